@@ -1,0 +1,80 @@
+"""Deterministic synthetic weights / inputs for the sampling hot path.
+
+There is no network for checkpoints, so tests, goldens and bench.py all use weights
+generated on the CPU from (name, shape, seed).  The reference initialises several
+tensors to exactly zero (adaLN-zero, final_layer.linear, cap_embedder[-1];
+reference dit/dit_models_xformers.py:807-819, dit/dit_i23d.py:207-217) which would
+make every denoiser output 0 and parity vacuous - so every tensor gets a small
+random value here.  torch's CPU generator is bit-reproducible
+for a given torch build, which is what lets a golden output computed in the build
+container be compared on the GPU box without shipping the weights.
+"""
+import zlib
+
+import torch
+
+
+def synth_tensor(name, shape, seed=0):
+    g = torch.Generator(device='cpu')
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    r = torch.randn(shape, generator=g, dtype=torch.float32)
+    leaf = name.rsplit('.', 1)[-1]
+    if 'pos_embed' in name:
+        raise ValueError('pos_embed is computed, not synthesised')
+    if name.endswith('scale_shift_table'):
+        return r / shape[-1] ** 0.5
+    if leaf == 'weight' and len(shape) == 1:                 # norm scales
+        return 1.0 + 0.05 * r
+    if leaf == 'bias' or len(shape) == 1:
+        return 0.02 * r
+    if 'triplane_decoder' in name or name.startswith('net.'):  # OSGDecoder FullyConnectedLayer: N(0,1)
+        return r
+    if 'adaLN_modulation' in name:
+        return 0.02 * r
+    if 'final_layer.linear' in name:
+        return 0.02 * r
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return r * (0.7 / fan_in ** 0.5)
+
+
+def synth_state_dict(shapes, seed=0, computed=None):
+    """shapes: {name: shape}.  computed: {name: tensor} for deterministic non-random
+    entries (pos_embed)."""
+    computed = computed or {}
+    out = {}
+    for k, shp in shapes.items():
+        out[k] = computed[k].clone() if k in computed else synth_tensor(k, shp, seed)
+    return out
+
+
+def synth_input(name, shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cpu')
+    g.manual_seed((zlib.crc32(('in:' + name).encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32) * scale
+
+
+def orbit_cameras(n_views, radius=1.7719, elevation_deg=15.0, focal=1.3889):
+    """[V,25] cameras on an orbit looking at the origin (OpenCV cam2world, normalised
+    intrinsics fx=fy=focal, cx=cy=0.5) - the layout of the reference's
+    assets/objv_eval_pose.pt (16 cam2world + 9 intrinsics)."""
+    import math
+    cams = []
+    for i in range(n_views):
+        az = 2 * math.pi * i / n_views
+        el = math.radians(elevation_deg)
+        pos = torch.tensor([radius * math.cos(el) * math.cos(az),
+                            radius * math.cos(el) * math.sin(az),
+                            radius * math.sin(el)])
+        fwd = -pos / pos.norm()                               # camera +z looks at the origin
+        up = torch.tensor([0., 0., 1.])
+        right = torch.linalg.cross(fwd, up)
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)                 # OpenCV: +y is down
+        c2w = torch.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
+        K = torch.tensor([[focal, 0, 0.5], [0, focal, 0.5], [0, 0, 1.]])
+        cams.append(torch.cat([c2w.reshape(-1), K.reshape(-1)]))
+    return torch.stack(cams)

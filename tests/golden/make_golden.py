@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python
+(imported from /root/reference through ref_shims.py) and, in the same pass, check that
+oracle/ reproduces it.  Runs ONLY in the build container (the reference does not travel).
+
+    python tests/golden/make_golden.py [section ...]
+
+Weights and inputs are synthesised deterministically from (name, shape, seed)
+(ln3diff_amd/synth.py), so a fixture holds only small outputs plus the shape manifest;
+the GPU box regenerates the identical weights/inputs.  What is data here is: inputs'
+recipe (names/seeds), expected outputs, and key/shape manifests of the reference
+modules.  No reference source text is stored.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+dmx = ref_shims.ref_dit_modules()
+
+from ln3diff_amd.synth import synth_state_dict, synth_input, orbit_cameras  # noqa: E402
+from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec  # noqa: E402
+
+torch.set_grad_enabled(False)
+TOL = 2e-5
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(name, got, want, tol=TOL):
+    e = relerr(got, want)
+    flag = 'OK ' if e <= tol else 'BAD'
+    print(f'  [{flag}] {name}: rel-L2 {e:.3e} (max|d| {float((got - want).abs().max()):.3e})')
+    assert e <= tol, name
+    return e
+
+
+def load_synth(module, seed=0):
+    sd = module.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    computed = {k: v for k, v in sd.items() if 'pos_embed' in k}
+    new = synth_state_dict(shapes, seed, computed)
+    module.load_state_dict(new, strict=True)
+    return {k: v.clone() for k, v in module.state_dict().items()}, shapes
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+def manifest_json(shapes):
+    return np.frombuffer(json.dumps({k: list(v) for k, v in shapes.items()}).encode(), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ T23D
+def build_t23d(hidden, depth, heads):
+    from dit.dit_trilatent import DiT_TriLatent
+    from dit.dit_models_xformers import TextCondDiTBlock
+    m = DiT_TriLatent(input_size=32, patch_size=2, in_channels=4, hidden_size=hidden, depth=depth,
+                      num_heads=heads, num_classes=0, learn_sigma=False, context_dim=768,
+                      roll_out=True, vit_blk=TextCondDiTBlock)
+    return m.eval()
+
+
+def sec_t23d():
+    print('== T23D DiT forward (reference DiT_TriLatent vs oracle.dit.t23d_forward)')
+    # tiny
+    m = build_t23d(128, 2, 2)
+    pe_ref = m.pos_embed.clone()
+    check('pos_embed(3,256) D=128', odit.trilatent_pos_embed(128), pe_ref, 1e-6)
+    sd, shapes = load_synth(m, 0)
+    x = synth_input('x', (2, 12, 32, 32), 0)
+    t = torch.tensor([999., 37.])
+    ctx = synth_input('ctx', (2, 77, 768), 0)
+    y_ref = m(x, t, ctx)
+    y_or = odit.t23d_forward(sd, x, t, ctx, 2)
+    check('tiny D128 L2 forward', y_or, y_ref)
+    save('t23d_tiny', y=y_ref, t=t, manifest=manifest_json(shapes))
+
+    for arch, B in (('DiT-B/2', 1), ('DiT-L/2', 2)):
+        hidden, depth, heads = odit.DIT_CONFIGS[arch]
+        t0 = time.time()
+        m = build_t23d(hidden, depth, heads)
+        sd, shapes = load_synth(m, 0)
+        x = synth_input('x', (B, 12, 32, 32), 0)
+        t = torch.tensor([500., 999.][:B])
+        ctx = synth_input('ctx', (B, 77, 768), 0)
+        y_ref = m(x, t, ctx)
+        y_or = odit.t23d_forward(sd, x, t, ctx, heads)
+        check(f'{arch} forward B={B}', y_or, y_ref)
+        tag = arch.replace('/', '').replace('-', '_').lower()
+        save(f't23d_{tag}', y=y_ref, t=t, manifest=manifest_json(shapes))
+        print(f'  ({arch}: {time.time() - t0:.1f}s)')
+        if arch == 'DiT-B/2':
+            sec_config1(m, sd, heads)
+        del m, sd
+
+
+# ------------------------------------------------- config 1: DiT-B/2 50-step p_sample_loop
+def sec_config1(m, sd, heads):
+    print('== BASELINE config 1: DiT-B/2, SpacedDiffusion("50").p_sample_loop, B=1')
+    from guided_diffusion import gaussian_diffusion as gd
+    from guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, '50'),
+                           betas=gd.get_named_beta_schedule('linear', 1000),
+                           model_mean_type=gd.ModelMeanType.EPSILON,
+                           model_var_type=gd.ModelVarType.FIXED_LARGE,
+                           loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    tabs = osamp.SpacedTables('50')
+    assert tabs.timestep_map == diff.timestep_map
+    for nm in ('betas', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
+               'posterior_mean_coef1', 'posterior_mean_coef2'):
+        assert np.array_equal(getattr(tabs, nm), getattr(diff, nm)), nm
+    ctx = synth_input('ctx', (1, 77, 768), 1)
+    z = synth_input('z', (1, 12, 32, 32), 1)
+
+    class Adapter:                       # what the engines expose to _WrappedModel
+        def apply_model_inference(self, x, t, c, **kw):
+            return m(x, t, c)
+    torch.manual_seed(1234)
+    t0 = time.time()
+    y_ref = diff.p_sample_loop(Adapter(), (1, 12, 32, 32), cond=ctx, noise=z.clone(),
+                               clip_denoised=False, mixing_normal=False, device='cpu')
+    print(f'  reference loop {time.time() - t0:.1f}s')
+    torch.manual_seed(1234)
+    noises = [torch.randn(1, 12, 32, 32) for _ in range(50)]
+    trace = []
+    y_or = osamp.ddpm_p_sample_loop(lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads),
+                                    z.clone(), noises, ctx, tabs, trace=trace)
+    check('config1 final latent', y_or, y_ref, 1e-4)
+    save('config1_ditb2_ddpm50', final=y_ref, step0=trace[0], step24=trace[24],
+         noise_seed=np.array(1234))
+
+
+# ------------------------------------------------------------- EDM / DDPM on tiny DiT
+def sec_samplers():
+    print('== samplers on the tiny T23D DiT')
+    m = build_t23d(128, 2, 2)
+    sd, _ = load_synth(m, 0)
+    B = 2
+    z = synth_input('z', (B, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (B, 77, 768), 41), 'vector': synth_input('v', (B, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+
+    # --- sgm EulerEDMSampler + DiscreteDenoiser(EpsScaling, LegacyDDPM) + VanillaCFG(6.5)
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    import sgm.util as sgm_util
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    for steps in (250, 10):
+        sampler = EulerEDMSampler(discretization_config=dc, num_steps=steps,
+                                  guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG',
+                                                 'params': {'scale': 6.5}}, device='cpu')
+        den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                               num_idx=1000, discretization_config=dc, do_append_zero=False,
+                               quantize_c_noise=True, flip=True)
+        sig_ref = sampler.discretization(steps, device='cpu')
+        check(f'sigma table n={steps}', osamp.legacy_ddpm_sigmas(steps), sig_ref, 0)
+        check('denoiser table', osamp.discrete_denoiser_table(), den.sigmas, 0)
+        seen_t = []
+
+        def net(x, t, c, **kw):
+            seen_t.append(t.clone())
+            return m(x, t, c)
+        y_ref = sampler(lambda x, s, c: den(net, x, s, c), z.clone(), cond, uc)
+        trace = []
+        y_or = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2),
+                                      z.clone(), cond, uc, steps, 6.5, trace)
+        check(f'EulerEDM {steps} steps final latent', y_or, y_ref, 2e-4)
+        save(f'edm_tiny_{steps}', final=y_ref, first=trace[0], mid=trace[steps // 2],
+             sigmas=sig_ref, idx_first=seen_t[0], idx_last=seen_t[-1])
+
+    # --- guided_diffusion p_sample_loop '250'
+    from guided_diffusion import gaussian_diffusion as gd
+    from guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    for spec in ('250', 'ddim250'):
+        assert osamp.space_timesteps(1000, spec) == space_timesteps(1000, spec)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, '250'),
+                           betas=gd.get_named_beta_schedule('linear', 1000),
+                           model_mean_type=gd.ModelMeanType.EPSILON,
+                           model_var_type=gd.ModelVarType.FIXED_LARGE,
+                           loss_type=gd.LossType.MSE, rescale_timesteps=False)
+
+    class Adapter:
+        def apply_model_inference(self, x, t, c, **kw):
+            return m(x, t, c)
+    torch.manual_seed(7)
+    y_ref = diff.p_sample_loop(Adapter(), (B, 12, 32, 32), cond=cond['crossattn'], noise=z.clone(),
+                               clip_denoised=False, mixing_normal=False, device='cpu')
+    torch.manual_seed(7)
+    noises = [torch.randn(B, 12, 32, 32) for _ in range(250)]
+    tabs = osamp.SpacedTables('250')
+    y_or = osamp.ddpm_p_sample_loop(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2),
+                                    z.clone(), noises, cond['crossattn'], tabs)
+    check('p_sample_loop 250 final latent', y_or, y_ref, 2e-4)
+    save('ddpm_tiny_250', final=y_ref, noise_seed=np.array(7))
+
+
+# ------------------------------------------------------------------ I23D
+def build_i23d(hidden, depth, heads):
+    from dit.dit_i23d import DiT_I23D_PixelArt
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DiT_I23D_PixelArt(input_size=32, patch_size=2, in_channels=4, hidden_size=hidden, depth=depth,
+                              num_heads=heads, num_classes=0, learn_sigma=False, context_dim=1024,
+                              roll_out=True, pooling_ctx_dim=768)
+    return m.eval()
+
+
+def sec_i23d():
+    print('== I23D DiT-PixArt forward_with_cfg + flow-matching Euler')
+    m = build_i23d(128, 2, 2)
+    sd, shapes = load_synth(m, 0)
+    B = 2
+    x = synth_input('x', (2 * B, 12, 32, 32), 0)
+    t = torch.tensor([0.3, 0.3, 0.3, 0.3])
+    ctx = {'crossattn': synth_input('ca', (2 * B, 256, 2048), 0), 'vector': synth_input('v', (2 * B, 768), 0)}
+    y_ref = m.forward_with_cfg(x, t, ctx, 4.0)
+    y_or = odit.i23d_forward_with_cfg(sd, x, t, ctx, 4.0, 2)
+    check('tiny I23D forward_with_cfg', y_or, y_ref)
+    save('i23d_tiny', y=y_ref, t=t, manifest=manifest_json(shapes))
+
+    # flow matching: transport.Sampler(...).sample_ode('euler', 50)
+    from transport import create_transport, Sampler
+    tr = create_transport(path_type='Linear', prediction='velocity', snr_type='lognorm')
+    z = synth_input('z', (B, 12, 32, 32), 42)
+    zs = torch.cat([z, z], 0)
+    cond = {'crossattn': synth_input('ca', (B, 256, 2048), 42), 'vector': synth_input('v', (B, 768), 42)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    context = {k: torch.cat([cond[k], uc[k]], 0) for k in cond}      # flow matching: [c, uc]
+    for method, steps in (('euler', 50), ('heun', 10)):
+        fn = Sampler(tr).sample_ode(sampling_method=method, num_steps=steps)
+        y_ref = fn(zs.clone(), m.forward_with_cfg, context=context, cfg_scale=4.0)[-1].chunk(2)[0]
+        y_or = osamp.flow_ode_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], kw['cfg_scale'], 2),
+                                     zs.clone(), steps, method, context=context, cfg_scale=4.0).chunk(2)[0]
+        check(f'flow {method} num_steps={steps} final latent', y_or, y_ref, 2e-4)
+        save(f'flow_tiny_{method}{steps}', final=y_ref)
+
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = build_i23d(hidden, depth, heads)
+    sd, shapes = load_synth(m, 0)
+    x = synth_input('x', (2, 12, 32, 32), 0)
+    t = torch.tensor([0.5, 0.5])
+    ctx = {'crossattn': synth_input('ca', (2, 256, 2048), 0), 'vector': synth_input('v', (2, 768), 0)}
+    y_ref = m.forward_with_cfg(x, t, ctx, 4.0)
+    y_or = odit.i23d_forward_with_cfg(sd, x, t, ctx, 4.0, heads)
+    check('DiT-PixArt-L/2 forward_with_cfg', y_or, y_ref)
+    save('i23d_pixart_l2', y=y_ref, t=t, manifest=manifest_json(shapes))
+
+
+SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d}
+
+if __name__ == '__main__':
+    from make_golden_render import sec_render, sec_decoder   # noqa: E402
+    SECTIONS.update(render=sec_render, decoder=sec_decoder)
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        t0 = time.time()
+        SECTIONS[s]()
+        print(f'-- {s} done in {time.time() - t0:.1f}s')
