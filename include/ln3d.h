@@ -1,0 +1,194 @@
+/* ln3d.h - C ABI of libln3d_hip.so: the MI355X (gfx950) kernels behind LN3Diff's
+ * text/image->3D sampling hot path.
+ *
+ * The reference (NIRVANALAN/LN3Diff) has NO C/FFI seam on this path: its seam is Python
+ * module surfaces plus calls into third-party fused ops.  Each entry point
+ * below names the reference call it replaces.  Conventions:
+ *   - every pointer is a caller-owned DEVICE pointer (HBM), contiguous in the documented
+ *     layout; no ownership transfer, no allocation, no host sync inside;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it;
+ *   - return 0 on success, negative LN3D_ERR_* otherwise (ln3d_strerror());
+ *   - bf16 tensors are raw uint16 bfloat16; "f32" is IEEE float;
+ *   - random numbers are never drawn inside: noise / jitter are input pointers.
+ */
+#ifndef LN3D_H
+#define LN3D_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LN3D_OK 0
+#define LN3D_ERR_BAD_ARG (-1)
+#define LN3D_ERR_LAUNCH (-2)
+#define LN3D_ERR_UNSUPPORTED (-3)
+
+const char* ln3d_strerror(int code);
+int ln3d_abi_version(void);
+
+/* ---------------------------------------------------------------- GEMM with fused epilogues
+ * out[m, n] = epilogue( sum_k X[m,k] * W[n,k] + bias[n] ),  X:[M,K] bf16 (tokens), W:[N,K] bf16
+ * (torch.nn.Linear weight layout).  fp32 accumulation on MFMA 32x32x16 bf16.  K % 64 == 0, N % 4 == 0.
+ * Replaces: torch.nn.Linear / F.linear inside
+ *   vit/vision_transformer.py:112,121 (qkv, proj), ldm/modules/attention.py:279-283,307 (to_q/k/v/out),
+ *   xformers FusedMLP at dit/dit_models_xformers.py:278-283, adaLN at :285-286,311-312,
+ *   TimestepEmbedder :94-98, CaptionEmbedder :197-201, and the 1x1/3x3 convs of
+ *   ldm/modules/diffusionmodules/model.py via im2col (ln3d_im2col3x3).
+ */
+enum {
+  LN3D_EPI_F32 = 0,        /* out0 f32 [M,ldo]                                             */
+  LN3D_EPI_BF16 = 1,       /* out0 bf16 [M,ldo]                                            */
+  LN3D_EPI_GELU_ERF = 2,   /* out0 bf16 = gelu_erf(.)   (xformers Activation.GeLU)          */
+  LN3D_EPI_GELU_TANH = 3,  /* out0 bf16 = gelu_tanh(.)  (CaptionEmbedder approx_gelu)       */
+  LN3D_EPI_SILU = 4,       /* out0 bf16 = silu(.)                                          */
+  LN3D_EPI_GATE_RES = 5,   /* out0 f32 [M,ldo] += gate * (.) ; optional out1 bf16 copy      */
+  LN3D_EPI_HEADS = 6,      /* split columns into heads: out{0,1,2} bf16, see below          */
+  LN3D_EPI_F32_SILU = 7    /* out0 f32 raw and out1 bf16 = silu(.)                           */
+};
+
+typedef struct {
+  const void* X; int64_t ldx;   /* bf16 [M, ldx]  */
+  const void* W; int64_t ldw;   /* bf16 [N, ldw]  */
+  const float* bias;            /* [N] or NULL    */
+  int M, N, K;
+  int epilogue;
+  void* out0; void* out1; void* out2;
+  int64_t ldo;
+  /* GATE_RES: gate[(m / gate_rows) * gate_ld + n] (f32), NULL = 1.  */
+  const float* gate; int gate_rows; int64_t gate_ld;
+  /* HEADS: column n -> which = n / (heads*head_dim), h, d; row m -> b = m / tokens, t = m % tokens.
+   *   which w writes out{w}: layout [B, heads, tok_pad, head_dim] if !(transpose_mask>>w & 1)
+   *   else [B, heads, head_dim, tok_pad] (V^T for the attention kernel's PV operand).       */
+  int tokens; int tok_pad; int heads; int head_dim; int transpose_mask;
+} ln3d_gemm_args;
+
+int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------- fused attention
+ * O[b, q, h*Dh + d] = softmax_k(scale * Q.K^T) V, bf16 in/out, fp32 softmax, MFMA 32x32x16.
+ *   Q  : bf16 [B, H, Nq_pad, Dh]   K : bf16 [B, H, Nk_pad, Dh]   Vt : bf16 [B, H, Dh, Nk_pad]
+ *   O  : bf16 [B, Nq, ldo]  (only rows q < Nq written).  Keys k >= Nk are masked; Nk_pad % 64 == 0 and
+ *   the padded K / Vt entries must be finite (zero).  Dh in {64, 128}.
+ * Replaces xformers.ops.memory_efficient_attention at vit/vision_transformer.py:118,
+ *   ldm/modules/attention.py:297 and ldm/modules/diffusionmodules/model.py:262.
+ */
+typedef struct {
+  const void* Q; const void* K; const void* Vt; void* O;
+  int B, H, Nq, Nq_pad, Nk, Nk_pad, Dh;
+  int64_t ldo;
+  float scale;
+} ln3d_attn_args;
+int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream);
+
+/* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
+ * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40) */
+int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, float eps, void* stream);
+
+/* ---------------------------------------------------------------- norm + modulation
+ * y[r, :] = norm(x[r, :]) * (1 + scale) + shift  -> bf16, one wavefront per row, fp32 statistics.
+ *   kind 0: LayerNorm(eps, no affine)   (dit/dit_models_xformers.py:249-258, modulate :48)
+ *   kind 1: RMSNorm(eps) * weight        (dit/norm.py:27-40, t2i_modulate :52)
+ *   shift/scale: f32, element [ (r / mod_rows) * mod_ld + d ]; NULL = no modulation.
+ *   table (optional f32 [D] each): added to shift / scale (PixArt scale_shift_table rows).
+ *   output row = (r / rows_in) * rows_out + (r % rows_in)   (rows_out > rows_in leaves room for
+ *   the appended DINO tokens, dit/dit_models_xformers.py:522-526).  D % 128 == 0, D <= 1152.
+ */
+typedef struct {
+  const float* x; void* y; int64_t rows; int D;
+  int kind; float eps; const float* weight;
+  const float* shift; const float* scale; int mod_rows; int64_t mod_ld;
+  const float* shift_table; const float* scale_table;
+  int rows_in; int rows_out;
+} ln3d_norm_args;
+int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream);
+
+/* ---------------------------------------------------------------- DiT boundary ops */
+/* TimestepEmbedder.timestep_embedding (dit/dit_models_xformers.py:101-122): t[B] f32 -> bf16 [B,256] = [cos|sin] */
+int ln3d_timestep_embedding(const float* t, void* out_bf16, int B, int dim, void* stream);
+
+/* y_bf16[i] = act(a[i] + b[i])  (b may be NULL); act 0 = identity, 1 = SiLU; optional f32 copy of a+b */
+int ln3d_add_act_cast(const float* a, const float* b, void* y_bf16, float* sum_f32, int64_t n, int act, void* stream);
+int ln3d_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* DiT_TriLatent patchify + x_embedder + pos_embed (dit/dit_trilatent.py:93-98):
+ *   x f32 [Bx, C*3, S, S] (channel = c*3 + n), network batch Bn >= Bx uses sample b % Bx;
+ *   optional in_scale[Bn] multiplies the input (EDM c_in, sgm denoiser.py:36-39);
+ *   w f32 [D, C*p*p], bias [D], pos f32 [3*L, D]  ->  tokens f32 [Bn, 3*L, D]                         */
+int ln3d_patch_embed(const float* x, const float* in_scale, const float* w, const float* bias,
+                     const float* pos, float* tokens, int Bx, int Bn, int C, int S, int p, int D, void* stream);
+
+/* FinalLayer / T2IFinalLayer + unpatchify (dit/dit_models_xformers.py:655-678, :61-84, :821-835,
+ * dit/dit_trilatent.py:128-140): LN(eps 1e-6) -> *(1+scale)+shift -> Linear(D -> p*p*C) -> [Bn, C*3, S, S] f32.
+ *   shift/scale f32 per sample at [b*mod_ld + d]; optional tables added.                              */
+int ln3d_final_layer(const float* tokens, const float* shift, const float* scale, int64_t mod_ld,
+                     const float* shift_table, const float* scale_table,
+                     const float* w, const float* bias, float* out,
+                     int Bn, int C, int S, int p, int D, void* stream);
+
+/* ---------------------------------------------------------------- sampler steps (elementwise, f32)
+ * EulerEDMSampler step with VanillaCFG on the eps-model (sgm sampling.py:93-104, guiders.py:29-42,
+ * denoiser.py:36-41, sampling_utils.py:34): eps[2B,...] = [uncond ; cond] network output on x*c_in.   */
+int ln3d_edm_euler_step(float* x, const float* eps2, float sigma, float sigma_next, float cfg_scale,
+                        int64_t n_per_batch_total, void* stream);
+/* GaussianDiffusion.p_sample, EPSILON / FIXED_LARGE (guided_diffusion/gaussian_diffusion.py:422-427,
+ * 252-271, 535-545): x <- c1*x0 + c2*x + nonzero*exp(0.5*logvar)*noise, x0 = a*x - b*eps (opt. clip)  */
+int ln3d_ddpm_step(float* x, const float* eps, const float* noise, float sqrt_recip, float sqrt_recipm1,
+                   float coef1, float coef2, float sigma_t, int clip, int64_t n, void* stream);
+/* flow matching Euler + CFG (transport/integrators.py:101-120, dit/dit_i23d.py:155-168):
+ * v[2B] = [cond ; uncond]; x[2B] (both halves updated identically): x += dt * (vu + s*(vc - vu))       */
+int ln3d_flow_euler_step(float* x2, const float* v2, float dt, float cfg_scale, int64_t n_half, void* stream);
+/* y = a*x + b*y (axpby, f32) - Heun / generic combinations */
+int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- tri-plane renderer
+ * planes: f32 channel-last [NP, 3, H, W, 32]  (reference layout is [NP, 96, H, W] = (n c) h w;
+ * ln3d_planes_to_channel_last converts).  One wavefront per ray.
+ */
+int ln3d_planes_to_channel_last(const float* planes_nchw, float* planes_nhwc, int NP, int C, int H, int W, void* stream);
+int ln3d_planes_to_nchw(const float* planes_nhwc, float* planes_nchw, int NP, int C, int H, int W, void* stream);
+#define LN3D_RENDER_SCRATCH_FLOATS 4096   /* size of ln3d_render_args.scalars */
+
+typedef struct {
+  const float* planes; int H, W;        /* channel-last tri-planes                                 */
+  const int32_t* plane_index;           /* [V] which tri-plane each view renders                     */
+  const float* cams;                    /* [V,25] cam2world(16) + intrinsics(9)                      */
+  int V, res;                           /* rays per view = res*res                                   */
+  const float* dec_w0; const float* dec_b0;   /* OSGDecoder FC 32->64 (raw weights; gain 1/sqrt(32) applied inside) */
+  const float* dec_w1; const float* dec_b1;   /* FC 64->4 (gain 1/sqrt(64))                           */
+  const float* jitter;                  /* [V, M, S] stratified jitter in [0,1)                      */
+  const float* u_fine;                  /* [V*M, S] importance uniforms                              */
+  float box_warp, bbox_min, bbox_max;
+  int white_back;
+  /* outputs */
+  float* rgb;    /* [V,3,res,res] in [-1,1] */
+  float* depth;  /* [V,1,res,res] */
+  float* wsum;   /* [V,1,res,res] */
+  /* scratch */
+  float* ray_limits;  /* [V*M*2]  */
+  float* scalars;     /* [LN3D_RENDER_SCRATCH_FLOATS]: batch-global min/max words + packed decoder     */
+  /* optional debug outputs (may be NULL) */
+  float* coarse_sigma; /* [V,M,S] */
+  float* fine_depths;  /* [V,M,S] */
+} ln3d_render_args;
+/* Triplane.forward -> ImportanceRenderer.forward -> MipRayMarcher2 (nsr/triplane.py:505-750,
+ * nsr/volumetric_rendering/renderer.py:133-307, ray_marcher.py:26-68, ray_sampler.py:262-331),
+ * depth_resolution = depth_resolution_importance = 64 (Objaverse preset nsr/script_util.py:761-798). */
+int ln3d_render_triplane(const ln3d_render_args* a, void* stream);
+
+/* triplane_decode_grid / forward_points (vit/vit_triplane.py:2009-2112): points f32 [P,3] -> sigma[P], rgb[P,3] */
+int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P,
+                      const float* dec_w0, const float* dec_b0, const float* dec_w1, const float* dec_b1,
+                      float box_warp, float* sigma, float* rgb, void* stream);
+
+/* ---------------------------------------------------------------- conv decoder pieces (channel-last f32/bf16)
+ * GroupNorm(32, eps 1e-6, affine) + optional swish over x f32 [N, HW, C] -> bf16 (ldm model.py:45-51)        */
+int ln3d_groupnorm_swish(const float* x, const float* w, const float* b, void* y_bf16, float* stats_scratch /* [N*groups*2] */,
+                         int N, int HW, int C, int groups, float eps, int swish, void* stream);
+/* im2col for 3x3 pad 1 convs on channel-last bf16 [N,H,W,C] with optional nearest 2x upsample of the input
+ * (ldm model.py:54-70): out bf16 [N*Ho*Wo, Kpad], column = (ky*3+kx)*C + c, zero padded to Kpad             */
+int ln3d_im2col3x3(const void* x_bf16, void* col_bf16, int N, int H, int W, int C, int upsample, int Kpad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

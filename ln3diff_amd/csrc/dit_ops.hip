@@ -1,0 +1,292 @@
+// Memory-bound DiT boundary ops for gfx950: norm+modulate, embeddings, final layer, sampler steps.
+// All are one-pass, vectorised (8-16 B per lane), fp32 statistics; one wavefront (64 lanes) per row
+// for the row-wise ops, so reductions are pure cross-lane shuffles (no LDS, no barriers).
+#include "common.h"
+#include "../../include/ln3d.h"
+
+#define MAXV 9  // D <= 1152 = 9 * 128 (float2 per lane per 128 columns)
+
+// ------------------------------------------------------------------ norm + modulation
+struct NormP {
+  const float* x; bf16_t* y; int64_t rows; int D; int kind; float eps; const float* weight;
+  const float* shift; const float* scale; int mod_rows; int64_t mod_ld;
+  const float* shift_table; const float* scale_table; int rows_in, rows_out;
+};
+
+__global__ __launch_bounds__(256) void norm_modulate_kernel(NormP p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int nv = p.D / 128;
+  const float* xr = p.x + row * p.D;
+  float2 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[i].x + v[i].y; }
+  float mean = 0.f, rstd;
+  if (p.kind == 0) {
+    mean = wave_sum(s) / p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) { const float a = v[i].x - mean, b = v[i].y - mean; q += a * a + b * b; }
+    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) q += v[i].x * v[i].x + v[i].y * v[i].y;
+    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+  }
+  const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
+  bf16_t* yr = p.y + orow * p.D;
+  const int64_t mrow = (row / p.mod_rows) * p.mod_ld;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const int d = i * 128 + lane * 2;
+      float a = (v[i].x - mean) * rstd, b = (v[i].y - mean) * rstd;
+      if (p.weight) { const float2 w = *reinterpret_cast<const float2*>(p.weight + d); a *= w.x; b *= w.y; }
+      if (p.scale) {
+        float2 sc = *reinterpret_cast<const float2*>(p.scale + mrow + d);
+        float2 sh = *reinterpret_cast<const float2*>(p.shift + mrow + d);
+        if (p.scale_table) {
+          const float2 t0 = *reinterpret_cast<const float2*>(p.scale_table + d);
+          const float2 t1 = *reinterpret_cast<const float2*>(p.shift_table + d);
+          sc.x += t0.x; sc.y += t0.y; sh.x += t1.x; sh.y += t1.y;
+        }
+        a = a * (1.f + sc.x) + sh.x; b = b * (1.f + sc.y) + sh.y;
+      }
+      *reinterpret_cast<uint32_t*>(yr + d) = pack2bf(a, b);
+    }
+}
+
+extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
+  if (!a || !a->x || !a->y || a->D % 128 != 0 || a->D > 128 * MAXV || a->rows <= 0) return LN3D_ERR_BAD_ARG;
+  if ((a->scale == nullptr) != (a->shift == nullptr)) return LN3D_ERR_BAD_ARG;
+  if ((a->scale_table == nullptr) != (a->shift_table == nullptr)) return LN3D_ERR_BAD_ARG;
+  NormP p;
+  p.x = a->x; p.y = (bf16_t*)a->y; p.rows = a->rows; p.D = a->D; p.kind = a->kind; p.eps = a->eps; p.weight = a->weight;
+  p.shift = a->shift; p.scale = a->scale; p.mod_rows = a->mod_rows > 0 ? a->mod_rows : 1; p.mod_ld = a->mod_ld;
+  p.shift_table = a->shift_table; p.scale_table = a->scale_table;
+  p.rows_in = a->rows_in > 0 ? a->rows_in : (int)a->rows; p.rows_out = a->rows_out > 0 ? a->rows_out : p.rows_in;
+  hipLaunchKernelGGL(norm_modulate_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ small elementwise
+__global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float freq = expf(-logf(10000.0f) * (float)k / (float)half);
+  const float arg = t[b] * freq;
+  out[(int64_t)b * dim + k] = f2bf(cosf(arg));
+  out[(int64_t)b * dim + half + k] = f2bf(sinf(arg));
+}
+extern "C" int ln3d_timestep_embedding(const float* t, void* out, int B, int dim, void* stream) {
+  if (!t || !out || dim % 2) return LN3D_ERR_BAD_ARG;
+  const int n = B * dim / 2;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, B, dim);
+  return ln3d_check_launch();
+}
+
+__global__ void add_act_cast_kernel(const float* a, const float* b, bf16_t* y, float* sum, int64_t n, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = a[i] + (b ? b[i] : 0.f);
+  if (sum) sum[i] = v;
+  if (act == 1) v = silu(v);
+  if (y) y[i] = f2bf(v);
+}
+extern "C" int ln3d_add_act_cast(const float* a, const float* b, void* y, float* sum, int64_t n, int act, void* stream) {
+  if (!a || n <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(add_act_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, (bf16_t*)y, sum, n, act);
+  return ln3d_check_launch();
+}
+
+__global__ void cast_f32_bf16_kernel(const float4* x, uint2* y, int64_t n4) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const float4 v = x[i];
+    uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+    y[i] = o;
+  }
+}
+extern "C" int ln3d_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+  if (!x || !y || n % 4) return LN3D_ERR_BAD_ARG;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (uint2*)y, n4);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ patch embed (+pos embed)
+// tokens[b, n*L + (ph*G + pw), d] = bias[d] + pos[n*L + ..., d] + sum_{c,i,j} w[d, c, i, j] * s_b * x[b%Bx, c*3+n, p*ph+i, p*pw+j]
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* x, const float* in_scale, const float* w, const float* bias,
+                                                          const float* pos, float* tokens, int Bx, int C, int S, int p, int D) {
+  const int G = S / p, L = G * G;
+  const int tok = blockIdx.x;            // b * 3L + n*L + l
+  const int b = tok / (3 * L), r = tok % (3 * L), n = r / L, l = r % L, ph = l / G, pw = l % G;
+  const int KK = C * p * p;              // <= 64
+  __shared__ float patch[64];
+  if (threadIdx.x < KK) {
+    const int c = threadIdx.x / (p * p), ij = threadIdx.x % (p * p), i = ij / p, j = ij % p;
+    const float sc = in_scale ? in_scale[b] : 1.0f;
+    patch[threadIdx.x] = sc * x[(((int64_t)(b % Bx) * C * 3 + c * 3 + n) * S + p * ph + i) * S + p * pw + j];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float acc = bias[d];
+    const float* wr = w + (int64_t)d * KK;
+    for (int k = 0; k < KK; ++k) acc += wr[k] * patch[k];
+    tokens[(int64_t)tok * D + d] = acc + pos[(int64_t)r * D + d];
+  }
+}
+extern "C" int ln3d_patch_embed(const float* x, const float* in_scale, const float* w, const float* bias, const float* pos,
+                                float* tokens, int Bx, int Bn, int C, int S, int p, int D, void* stream) {
+  if (!x || !w || !bias || !pos || !tokens || C * p * p > 64 || S % p) return LN3D_ERR_BAD_ARG;
+  const int L = (S / p) * (S / p);
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(Bn * 3 * L), dim3(256), 0, (hipStream_t)stream, x, in_scale, w, bias, pos, tokens, Bx, C, S, p, D);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ final layer (+unpatchify)
+struct FinalP {
+  const float* tokens; const float* shift; const float* scale; int64_t mod_ld;
+  const float* shift_table; const float* scale_table; const float* w; const float* bias; float* out;
+  int Bn, C, S, p, D;
+};
+__global__ __launch_bounds__(256) void final_layer_kernel(FinalP q) {
+  const int lane = threadIdx.x & 63;
+  const int G = q.S / q.p, L = G * G;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= (int64_t)q.Bn * 3 * L) return;
+  const int b = (int)(tok / (3 * L)), r = (int)(tok % (3 * L)), n = r / L, l = r % L, ph = l / G, pw = l % G;
+  const int nv = q.D / 128;
+  const float* xr = q.tokens + tok * q.D;
+  float2 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[i].x + v[i].y; }
+  const float mean = wave_sum(s) / q.D;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { const float a = v[i].x - mean, c = v[i].y - mean; qq += a * a + c * c; }
+  const float rstd = rsqrtf(wave_sum(qq) / q.D + 1e-6f);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const int d = i * 128 + lane * 2;
+      float2 sc = *reinterpret_cast<const float2*>(q.scale + (int64_t)b * q.mod_ld + d);
+      float2 sh = *reinterpret_cast<const float2*>(q.shift + (int64_t)b * q.mod_ld + d);
+      if (q.scale_table) {
+        const float2 t0 = *reinterpret_cast<const float2*>(q.scale_table + d);
+        const float2 t1 = *reinterpret_cast<const float2*>(q.shift_table + d);
+        sc.x += t0.x; sc.y += t0.y; sh.x += t1.x; sh.y += t1.y;
+      }
+      v[i].x = (v[i].x - mean) * rstd * (1.f + sc.x) + sh.x;
+      v[i].y = (v[i].y - mean) * rstd * (1.f + sc.y) + sh.y;
+    }
+  const int NO = q.p * q.p * q.C;        // outputs per token, index o = (i*p + j)*C + c
+  for (int o = 0; o < NO; ++o) {
+    const float* wr = q.w + (int64_t)o * q.D;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const float2 ww = *reinterpret_cast<const float2*>(wr + i * 128 + lane * 2);
+        acc += ww.x * v[i].x + ww.y * v[i].y;
+      }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const int c = o % q.C, ij = o / q.C, i = ij / q.p, j = ij % q.p;
+      q.out[(((int64_t)b * q.C * 3 + c * 3 + n) * q.S + q.p * ph + i) * q.S + q.p * pw + j] = acc + q.bias[o];
+    }
+  }
+}
+extern "C" int ln3d_final_layer(const float* tokens, const float* shift, const float* scale, int64_t mod_ld,
+                                const float* shift_table, const float* scale_table, const float* w, const float* bias,
+                                float* out, int Bn, int C, int S, int p, int D, void* stream) {
+  if (!tokens || !shift || !scale || !w || !bias || !out || D % 128 || D > 128 * MAXV) return LN3D_ERR_BAD_ARG;
+  FinalP q{tokens, shift, scale, mod_ld, shift_table, scale_table, w, bias, out, Bn, C, S, p, D};
+  const int64_t ntok = (int64_t)Bn * 3 * (S / p) * (S / p);
+  hipLaunchKernelGGL(final_layer_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ sampler steps
+__global__ void edm_euler_step_kernel(float* x, const float* eps2, float sigma, float sigma_next, float scale, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  const float den_u = eps2[i] * (-sigma) + xv;          // DiscreteDenoiser: net*c_out + x*c_skip
+  const float den_c = eps2[n + i] * (-sigma) + xv;
+  const float den = den_u + scale * (den_c - den_u);    // VanillaCFG
+  const float d = (xv - den) / sigma;                   // to_d
+  x[i] = xv + d * (sigma_next - sigma);                 // euler_step
+}
+extern "C" int ln3d_edm_euler_step(float* x, const float* eps2, float sigma, float sigma_next, float cfg_scale, int64_t n, void* stream) {
+  if (!x || !eps2 || n <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(edm_euler_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps2, sigma, sigma_next, cfg_scale, n);
+  return ln3d_check_launch();
+}
+
+__global__ void ddpm_step_kernel(float* x, const float* eps, const float* noise, float a, float b, float c1, float c2,
+                                 float sig, int clip, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  float x0 = a * xv - b * eps[i];
+  if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  const float mean = c1 * x0 + c2 * xv;
+  x[i] = mean + sig * noise[i];
+}
+extern "C" int ln3d_ddpm_step(float* x, const float* eps, const float* noise, float sqrt_recip, float sqrt_recipm1, float coef1,
+                              float coef2, float sigma_t, int clip, int64_t n, void* stream) {
+  if (!x || !eps || !noise || n <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, sqrt_recip,
+                     sqrt_recipm1, coef1, coef2, sigma_t, clip, n);
+  return ln3d_check_launch();
+}
+
+__global__ void flow_euler_step_kernel(float* x2, const float* v2, float dt, float scale, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float vc = v2[i], vu = v2[n + i];
+  const float v = vu + scale * (vc - vu);
+  x2[i] += dt * v;
+  x2[n + i] += dt * v;
+}
+extern "C" int ln3d_flow_euler_step(float* x2, const float* v2, float dt, float cfg_scale, int64_t n_half, void* stream) {
+  if (!x2 || !v2 || n_half <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(flow_euler_step_kernel, dim3((unsigned)((n_half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x2, v2, dt, cfg_scale, n_half);
+  return ln3d_check_launch();
+}
+
+__global__ void axpby_kernel(const float* x, float* y, float a, float b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + b * y[i];
+}
+extern "C" int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, n);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" const char* ln3d_strerror(int code) {
+  switch (code) {
+    case LN3D_OK: return "ok";
+    case LN3D_ERR_BAD_ARG: return "bad argument (null pointer, unsupported shape or alignment)";
+    case LN3D_ERR_LAUNCH: return "HIP kernel launch failed";
+    case LN3D_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+extern "C" int ln3d_abi_version(void) { return 1; }

@@ -1,0 +1,239 @@
+// bf16 GEMM with fused epilogues for gfx950 (CDNA4): out[m,n] = epi(sum_k X[m,k] W[n,k] + bias[n]).
+//
+// Design (MI355X-first):
+//  * MFMA v_mfma_f32_32x32x16_bf16, 64-lane wavefronts.  The MFMA "A" operand is the WEIGHT tile
+//    (rows = output features) and the "B" operand the TOKEN tile, so the fp32 accumulator fragment
+//    of a lane holds 4 consecutive output FEATURES of one token ( row = (r&3)+8(r>>2)+4(lane>>5),
+//    col = lane&31 ) -> every epilogue store is a contiguous 8-byte (bf16) / 16-byte (f32) piece of
+//    an output row, and per-feature bias / per-(sample,feature) gates are 4-wide vector loads.
+//  * 128(features) x 128(tokens) x 64(K) block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles
+//    (64 accumulator VGPRs).  Both operands are K-contiguous in HBM ([rows, K] row-major), staged
+//    HBM -> VGPR (global_load_dwordx4, 8 lanes cover one 128-B row segment) -> LDS rows padded to
+//    144 B, which makes the ds_read_b128 fragment reads bank-conflict free (16 distinct rows of a
+//    b128 lane-group land on 16 distinct 16-B slots: 144*r mod 256).  Double-buffered LDS, the next
+//    tile's global loads are issued before the MFMA block of the current tile (latency hidden under
+//    16 MFMAs/wave), one barrier per K-tile.
+//  * Epilogues fused: bias, GELU(erf/tanh), SiLU, gate*out+residual (adaLN-zero gating into the fp32
+//    residual stream, optional bf16 copy), head split with V^T emission for the attention kernel.
+#include "common.h"
+#include "../../include/ln3d.h"
+
+#define BMF 128  // features per block
+#define BTK 128  // tokens per block
+#define BK 64
+#define ROWB 144                      // LDS bytes per tile row (128 + 16 pad)
+#define TILEB (128 * ROWB)            // 18432
+#define GEMM_LDS (4 * TILEB)          // 2 buffers x (W tile + X tile)
+
+struct GemmP {
+  const bf16_t* X; const bf16_t* W; const float* bias;
+  int64_t ldx, ldw, ldo;
+  int M, N, K;
+  void* out0; void* out1; void* out2;
+  const float* gate; int gate_rows; int64_t gate_ld;
+  int tokens, tok_pad, heads, head_dim, transpose_mask;
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float v0, float v1, float v2, float v3) {
+  // 4 consecutive features fb..fb+3 of token `tok` (all in range, fb % 4 == 0)
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + fb);
+    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+  }
+  if constexpr (EPI == LN3D_EPI_F32) {
+    *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb) = make_float4(v0, v1, v2, v3);
+  } else if constexpr (EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH ||
+                       EPI == LN3D_EPI_SILU) {
+    if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+    if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+    uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
+    *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (int64_t)tok * p.ldo + fb) = o;
+  } else if constexpr (EPI == LN3D_EPI_F32_SILU) {
+    *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb) = make_float4(v0, v1, v2, v3);
+    uint2 o; o.x = pack2bf(silu(v0), silu(v1)); o.y = pack2bf(silu(v2), silu(v3));
+    *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)tok * p.ldo + fb) = o;
+  } else if constexpr (EPI == LN3D_EPI_GATE_RES) {
+    if (p.gate) {
+      const float4 g = *reinterpret_cast<const float4*>(p.gate + (int64_t)(tok / p.gate_rows) * p.gate_ld + fb);
+      v0 *= g.x; v1 *= g.y; v2 *= g.z; v3 *= g.w;
+    }
+    float4* xp = reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb);
+    float4 x = *xp;
+    x.x += v0; x.y += v1; x.z += v2; x.w += v3;
+    *xp = x;
+    if (p.out1) {
+      uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
+      *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)tok * p.ldo + fb) = o;
+    }
+  } else if constexpr (EPI == LN3D_EPI_HEADS) {
+    const int dm = p.heads * p.head_dim;
+    const int which = fb / dm;
+    const int rem = fb - which * dm;
+    const int h = rem / p.head_dim, d = rem - h * p.head_dim;
+    const int b = tok / p.tokens, t = tok - b * p.tokens;
+    bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+    const int64_t bh = (int64_t)b * p.heads + h;
+    if (!((p.transpose_mask >> which) & 1)) {
+      uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
+      *reinterpret_cast<uint2*>(dst + (bh * p.tok_pad + t) * p.head_dim + d) = o;
+    } else {
+      bf16_t* q = dst + (bh * p.head_dim + d) * p.tok_pad + t;
+      q[0] = f2bf(v0); q[p.tok_pad] = f2bf(v1); q[2 * (int64_t)p.tok_pad] = f2bf(v2); q[3 * (int64_t)p.tok_pad] = f2bf(v3);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wf = wid >> 1, wt = wid & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nft = (p.N + BMF - 1) / BMF;
+  const int ft = blockIdx.x % nft, tt = blockIdx.x / nft;
+  const int f0 = ft * BMF, t0 = tt * BTK;
+
+  // staging map: 8 lanes x 16 B cover one 128-B row segment; 32 rows per pass, 4 passes
+  const int c = tid & 7, r0 = tid >> 3;
+  const bf16_t* wsrc[4]; const bf16_t* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int rf = f0 + r0 + 32 * i; rf = rf < p.N ? rf : p.N - 1;
+    int rt = t0 + r0 + 32 * i; rt = rt < p.M ? rt : p.M - 1;
+    wsrc[i] = p.W + (int64_t)rf * p.ldw + c * 8;
+    xsrc[i] = p.X + (int64_t)rt * p.ldx + c * 8;
+  }
+  const int st_off = r0 * ROWB + c * 16;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const uint4*>(wsrc[i]);
+    rb[i] = *reinterpret_cast<const uint4*>(xsrc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<uint4*>(smem + st_off + i * 32 * ROWB) = ra[i];
+    *reinterpret_cast<uint4*>(smem + TILEB + st_off + i * 32 * ROWB) = rb[i];
+  }
+  __syncthreads();
+
+  const int a_off = (wf * 64 + l31) * ROWB + hi * 16;
+  const int b_off = TILEB + (wt * 64 + l31) * ROWB + hi * 16;
+
+  auto mma_tile = [&](const char* base) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 32 * ROWB + ks * 32);
+        b[i] = *reinterpret_cast<const bf16x8*>(base + b_off + i * 32 * ROWB + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int buf = kt & 1;
+    const int koff = (kt + 1) * BK;
+    // explicit scalars (not arrays): keeps the in-flight tile in VGPRs across the sched_barrier
+    const uint4 na0 = *reinterpret_cast<const uint4*>(wsrc[0] + koff);
+    const uint4 na1 = *reinterpret_cast<const uint4*>(wsrc[1] + koff);
+    const uint4 na2 = *reinterpret_cast<const uint4*>(wsrc[2] + koff);
+    const uint4 na3 = *reinterpret_cast<const uint4*>(wsrc[3] + koff);
+    const uint4 nx0 = *reinterpret_cast<const uint4*>(xsrc[0] + koff);
+    const uint4 nx1 = *reinterpret_cast<const uint4*>(xsrc[1] + koff);
+    const uint4 nx2 = *reinterpret_cast<const uint4*>(xsrc[2] + koff);
+    const uint4 nx3 = *reinterpret_cast<const uint4*>(xsrc[3] + koff);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+    mma_tile(smem + buf * 2 * TILEB);
+    __builtin_amdgcn_sched_barrier(0);
+    char* nb = smem + (buf ^ 1) * 2 * TILEB + st_off;
+    *reinterpret_cast<uint4*>(nb + 0 * 32 * ROWB) = na0;
+    *reinterpret_cast<uint4*>(nb + 1 * 32 * ROWB) = na1;
+    *reinterpret_cast<uint4*>(nb + 2 * 32 * ROWB) = na2;
+    *reinterpret_cast<uint4*>(nb + 3 * 32 * ROWB) = na3;
+    *reinterpret_cast<uint4*>(nb + TILEB + 0 * 32 * ROWB) = nx0;
+    *reinterpret_cast<uint4*>(nb + TILEB + 1 * 32 * ROWB) = nx1;
+    *reinterpret_cast<uint4*>(nb + TILEB + 2 * 32 * ROWB) = nx2;
+    *reinterpret_cast<uint4*>(nb + TILEB + 3 * 32 * ROWB) = nx3;
+    __syncthreads();
+  }
+  mma_tile(smem + ((nk - 1) & 1) * 2 * TILEB);
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tok = t0 + wt * 64 + j * 32 + l31;
+    if (tok >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = f0 + wf * 64 + i * 32 + 8 * g + 4 * hi;
+        if (fb < p.N)
+          epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch(const GemmP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    attr_set = true;
+  }
+  const int nft = (p.N + BMF - 1) / BMF, ntt = (p.M + BTK - 1) / BTK;
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nft * ntt), dim3(256), GEMM_LDS, s, p);
+  return ln3d_check_launch();
+}
+
+extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
+  if (!a || !a->X || !a->W || !a->out0) return LN3D_ERR_BAD_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0 || (a->N % 4) != 0) return LN3D_ERR_BAD_ARG;
+  if ((a->ldx % 8) != 0 || (a->ldw % 8) != 0) return LN3D_ERR_BAD_ARG;
+  GemmP p;
+  p.X = (const bf16_t*)a->X; p.W = (const bf16_t*)a->W; p.bias = a->bias;
+  p.ldx = a->ldx; p.ldw = a->ldw; p.ldo = a->ldo;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.out0 = a->out0; p.out1 = a->out1; p.out2 = a->out2;
+  p.gate = a->gate; p.gate_rows = a->gate_rows > 0 ? a->gate_rows : 1; p.gate_ld = a->gate_ld;
+  p.tokens = a->tokens; p.tok_pad = a->tok_pad; p.heads = a->heads; p.head_dim = a->head_dim;
+  p.transpose_mask = a->transpose_mask;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case LN3D_EPI_F32: return launch<LN3D_EPI_F32>(p, s);
+    case LN3D_EPI_BF16: return launch<LN3D_EPI_BF16>(p, s);
+    case LN3D_EPI_GELU_ERF: return launch<LN3D_EPI_GELU_ERF>(p, s);
+    case LN3D_EPI_GELU_TANH: return launch<LN3D_EPI_GELU_TANH>(p, s);
+    case LN3D_EPI_SILU: return launch<LN3D_EPI_SILU>(p, s);
+    case LN3D_EPI_GATE_RES: return launch<LN3D_EPI_GATE_RES>(p, s);
+    case LN3D_EPI_F32_SILU:
+      if (!a->out1) return LN3D_ERR_BAD_ARG;
+      return launch<LN3D_EPI_F32_SILU>(p, s);
+    case LN3D_EPI_HEADS:
+      if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens)
+        return LN3D_ERR_BAD_ARG;
+      return launch<LN3D_EPI_HEADS>(p, s);
+    default: return LN3D_ERR_UNSUPPORTED;
+  }
+}

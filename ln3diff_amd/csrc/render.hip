@@ -1,0 +1,455 @@
+// Fused tri-plane volumetric renderer for gfx950 (one wavefront per ray).
+//
+// Replaces, in ONE launch per batch of views (plus two tiny pre/post passes for the reference's
+// batch-global reductions): ray generation, ray/AABB limits, stratified sampling, tri-plane bilinear
+// gather (F.grid_sample x3), OSGDecoder MLP, MipRayMarcher2 compositing, importance sampling
+// (max/avg pool, cdf, searchsorted), the coarse+fine merge (torch.sort + gathers) and the final
+// compositing.  The reference materialises [V,3,M*S,32] features (1.6 GB per 256^2 view-pass) and
+// ~6 GB of HBM traffic per view; here nothing but the tri-plane texels and 5 floats per ray touch HBM.
+//
+// Wave mapping (64 lanes = the 64 coarse / 64 fine samples of one ray):
+//  * gather phase : 8 lanes per sample point, lane (g = lane>>3, c4 = lane&7) fetches channels 4c4..4c4+3
+//    of the 12 taps of point 8*it+g from CHANNEL-LAST planes [3][H][W][32] -> every wave-level load
+//    instruction touches 8 fully-used 128-B texels (coalesced), instead of 64 partially-used lines.
+//    The interpolated 32-vector is transposed through a per-wave LDS tile (row stride 36 floats,
+//    conflict-free for ds_read_b128) ...
+//  * MLP phase    : ... and each lane then runs the 32->64->4 decoder for ITS sample with the weights as
+//    wave-uniform scalar operands (s_load through the scalar cache; no LDS / VGPR traffic for weights).
+//  * compositing  : wavefront-level: neighbours by DPP/shuffle, transmittance by a wave prefix product,
+//    cdf by a wave prefix sum, searchsorted by a 6-step binary search on the per-wave LDS copy of the
+//    cdf, the coarse+fine merge by rank counting (no sort), final sums by wave reductions.
+#include "common.h"
+#include "../../include/ln3d.h"
+
+#define NS 64            // samples per pass (coarse == fine == 64, Objaverse preset)
+#define FROW 36          // floats per LDS feature row (32 + 4 pad)
+#define WAVE_LDS_FLOATS (NS * FROW)   // 2304 floats = 9216 B per wave
+#define DEC_OFF 16       // scalars[DEC_OFF..] = packed decoder: w0g[64*32], b0[64], w1g[4*64], b1[4]
+#define DEC_FLOATS (64 * 32 + 64 + 4 * 64 + 4)
+
+__device__ __forceinline__ uint32_t enc_f(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float softplus_fast(float x) {   // torch softplus(beta=1, threshold=20)
+  return x > 20.0f ? x : __logf(1.0f + __expf(x));
+}
+
+struct RenderP {
+  const float* planes; int H, W;
+  const int32_t* plane_index; const float* cams; int V, res;
+  const float* jitter; const float* u_fine;
+  float coord_scale, bbox_min, bbox_max; int white_back;
+  float* rgb; float* depth; float* wsum;
+  float* ray_limits; uint32_t* scal_u; const float* dec;
+  float* coarse_sigma; float* fine_depths;
+};
+
+// ------------------------------------------------------------------ ray generation + AABB limits
+__device__ __forceinline__ void make_ray(const float* cam, int res, int pix, float o[3], float d[3]) {
+  const float inv_res = 1.0f / (float)res, half = 0.5f / (float)res;
+  const int i = pix / res, j = pix - i * res;
+  const float x_cam = (float)j * inv_res + half, y_cam = (float)i * inv_res + half;
+  const float fx = cam[16], sk = cam[17], cx = cam[18], fy = cam[20], cy = cam[21];
+  const float xl = (x_cam - cx + cy * sk / fy - sk * y_cam / fy) / fx;
+  const float yl = (y_cam - cy) / fy;
+  float w[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    w[r] = cam[4 * r + 0] * xl + cam[4 * r + 1] * yl + cam[4 * r + 2] + cam[4 * r + 3];
+    o[r] = cam[4 * r + 3];
+    d[r] = w[r] - o[r];
+  }
+  const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+  d[0] /= nrm; d[1] /= nrm; d[2] /= nrm;
+}
+
+__device__ __forceinline__ void ray_box(const float o[3], const float d[3], float half, float& tmin_o, float& tmax_o) {
+  float inv[3]; int sg[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { inv[a] = 1.0f / d[a]; sg[a] = inv[a] < 0.f; }
+  auto bnd = [&](int s) { return s ? half : -half; };
+  float tmin = (bnd(sg[0]) - o[0]) * inv[0], tmax = (bnd(1 - sg[0]) - o[0]) * inv[0];
+  const float tymin = (bnd(sg[1]) - o[1]) * inv[1], tymax = (bnd(1 - sg[1]) - o[1]) * inv[1];
+  bool valid = !(tmin > tymax || tymin > tmax);
+  tmin = fmaxf(tmin, tymin); tmax = fminf(tmax, tymax);
+  const float tzmin = (bnd(sg[2]) - o[2]) * inv[2], tzmax = (bnd(1 - sg[2]) - o[2]) * inv[2];
+  valid = valid && !(tmin > tzmax || tzmin > tmax);
+  tmin = fmaxf(tmin, tzmin); tmax = fminf(tmax, tzmax);
+  tmin_o = valid ? tmin : -1.0f;
+  tmax_o = valid ? tmax : -2.0f;
+}
+
+__global__ void render_init_kernel(uint32_t* scal_u, float* dec, const float* w0, const float* b0, const float* w1, const float* b1) {
+  const int t = threadIdx.x + blockIdx.x * blockDim.x;
+  if (t == 0) { scal_u[0] = 0xffffffffu; scal_u[1] = 0u; scal_u[2] = 0xffffffffu; scal_u[3] = 0u; scal_u[4] = 0u; }
+  const float g0 = 1.0f / sqrtf(32.0f), g1 = 1.0f / sqrtf(64.0f);   // FullyConnectedLayer weight_gain
+  for (int i = t; i < DEC_FLOATS; i += blockDim.x * gridDim.x) {
+    float v;
+    if (i < 2048) v = w0[i] * g0;
+    else if (i < 2048 + 64) v = b0[i - 2048];
+    else if (i < 2048 + 64 + 256) v = w1[i - 2112] * g1;
+    else v = b1[i - 2368];
+    dec[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_half) {
+  const int M = p.res * p.res;
+  const int64_t nr = (int64_t)p.V * M;
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float tmn = 3.0e38f, tmx = -3.0e38f; int any = 0;
+  if (ray < nr) {
+    const int v = (int)(ray / M), pix = (int)(ray % M);
+    float o[3], d[3], a, b;
+    make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    ray_box(o, d, box_half, a, b);
+    p.ray_limits[2 * ray] = a; p.ray_limits[2 * ray + 1] = b;
+    if (b > a) { tmn = a; tmx = a; any = 1; }
+  }
+  tmn = wave_min(tmn); tmx = wave_max(tmx);
+  any = __any(any);
+  if ((threadIdx.x & 63) == 0 && any) {
+    atomicMin(&p.scal_u[0], enc_f(tmn));
+    atomicMax(&p.scal_u[1], enc_f(tmx));
+    atomicOr(&p.scal_u[4], 1u);
+  }
+}
+
+// ------------------------------------------------------------------ gather + decoder for the wave's 64 points
+// in : this lane's point (px,py,pz) in world units.  out: rgb[3], sigma (bbox filter applied).
+__device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, float* feat /*per-wave LDS*/,
+                                        const float* __restrict__ dec, float px, float py, float pz, int lane,
+                                        float rgb[3], float& sigma) {
+  const int g = lane >> 3, c4 = lane & 7;
+  const float sx = px * p.coord_scale, sy = py * p.coord_scale, sz = pz * p.coord_scale;
+  const int64_t plane_stride = (int64_t)p.H * p.W * 32;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int src = it * 8 + g;
+    const float qx = __shfl(sx, src, 64), qy = __shfl(sy, src, 64), qz = __shfl(sz, src, 64);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const float gx = pl == 0 ? qx : (pl == 1 ? qy : qz);     // (x,y) (y,z) (z,x)
+      const float gy = pl == 0 ? qy : (pl == 1 ? qz : qx);
+      const float ix = ((gx + 1.f) * p.W - 1.f) * 0.5f, iy = ((gy + 1.f) * p.H - 1.f) * 0.5f;
+      const float fx0 = floorf(ix), fy0 = floorf(iy);
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      const float w_nw = (fx0 + 1.f - ix) * (fy0 + 1.f - iy), w_ne = (ix - fx0) * (fy0 + 1.f - iy);
+      const float w_sw = (fx0 + 1.f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
+      const float* base = planes + pl * plane_stride + c4 * 4;
+      const bool xin0 = x0 >= 0 && x0 < p.W, xin1 = x0 + 1 >= 0 && x0 + 1 < p.W;
+      const bool yin0 = y0 >= 0 && y0 < p.H, yin1 = y0 + 1 >= 0 && y0 + 1 < p.H;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xin0 && yin0) t = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * p.W + x0) * 32);
+      s.x = t.x * w_nw; s.y = t.y * w_nw; s.z = t.z * w_nw; s.w = t.w * w_nw;
+      t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xin1 && yin0) t = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * p.W + x0 + 1) * 32);
+      s.x += t.x * w_ne; s.y += t.y * w_ne; s.z += t.z * w_ne; s.w += t.w * w_ne;
+      t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xin0 && yin1) t = *reinterpret_cast<const float4*>(base + ((int64_t)(y0 + 1) * p.W + x0) * 32);
+      s.x += t.x * w_sw; s.y += t.y * w_sw; s.z += t.z * w_sw; s.w += t.w * w_sw;
+      t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xin1 && yin1) t = *reinterpret_cast<const float4*>(base + ((int64_t)(y0 + 1) * p.W + x0 + 1) * 32);
+      s.x += t.x * w_se; s.y += t.y * w_se; s.z += t.z * w_se; s.w += t.w * w_se;
+      acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    }
+    const float third = 1.0f / 3.0f;  // mean over the 3 planes (torch: sum / 3)
+    acc.x = acc.x / 3.0f; acc.y = acc.y / 3.0f; acc.z = acc.z / 3.0f; acc.w = acc.w / 3.0f;
+    (void)third;
+    *reinterpret_cast<float4*>(feat + src * FROW + c4 * 4) = acc;
+  }
+  wave_sync();
+  float f[32];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(feat + lane * FROW + k * 4);
+    f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+  }
+  wave_sync();   // feat may be overwritten by the caller / next pass
+  const float* w0 = dec; const float* b0 = dec + 2048; const float* w1 = dec + 2112; const float* b1 = dec + 2368;
+  float o0 = b1[0], o1 = b1[1], o2 = b1[2], o3 = b1[3];
+#pragma unroll 4
+  for (int j = 0; j < 64; ++j) {
+    float h = b0[j];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) h += f[k] * w0[j * 32 + k];
+    h = softplus_fast(h);
+    o0 += h * w1[j]; o1 += h * w1[64 + j]; o2 += h * w1[128 + j]; o3 += h * w1[192 + j];
+  }
+  const bool inb = px >= p.bbox_min && px <= p.bbox_max && py >= p.bbox_min && py <= p.bbox_max && pz >= p.bbox_min &&
+                   pz <= p.bbox_max;
+  const float sg_fill = -3.4028234663852886e38f / 3.0f;   // nan_to_num(-inf) / SAFE_GUARD
+  sigma = inb ? o0 : sg_fill;
+  rgb[0] = inb ? (1.0f / (1.0f + __expf(-o1))) * 1.002f - 0.001f : 0.f;
+  rgb[1] = inb ? (1.0f / (1.0f + __expf(-o2))) * 1.002f - 0.001f : 0.f;
+  rgb[2] = inb ? (1.0f / (1.0f + __expf(-o3))) * 1.002f - 0.001f : 0.f;
+}
+
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {   // exclusive prefix product over lanes
+  float x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(x, o, 64); if (lane >= o) x *= y; }
+  const float e = __shfl_up(x, 1, 64);
+  return lane == 0 ? 1.0f : e;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+  float x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void render_kernel(RenderP p, const float* __restrict__ dec) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* feat = lds + wid * WAVE_LDS_FLOATS;       // 2304 floats; reused for cdf/bins/merge arrays between shading passes
+  const int M = p.res * p.res;
+  const int64_t nrays = (int64_t)p.V * M;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const bool any_valid = p.scal_u[4] != 0u;
+  const float gmin = dec_f(p.scal_u[0]), gmax = dec_f(p.scal_u[1]);
+  float dmin_l = 3.0e38f, dmax_l = -3.0e38f;
+
+  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < nrays; ray += nwaves) {
+    const int v = (int)(ray / M), pix = (int)(ray % M);
+    float o[3], d[3];
+    make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    float t0 = p.ray_limits[2 * ray], t1 = p.ray_limits[2 * ray + 1];
+    if (any_valid && !(t1 > t0)) { t0 = gmin; t1 = gmax; }    // renderer.py:151-155 (sic)
+    const float* planes = p.planes + (int64_t)p.plane_index[v] * 3 * p.H * p.W * 32;
+
+    // ---- coarse depths: linspace + jitter * delta
+    const float step = (float)lane / (float)(NS - 1);
+    const float delta = (t1 - t0) / (float)(NS - 1);
+    const float zc = (t0 + step * (t1 - t0)) + p.jitter[ray * NS + lane] * delta;
+    float rgbc[3], sigc;
+    shade64(p, planes, feat, dec, o[0] + zc * d[0], o[1] + zc * d[1], o[2] + zc * d[2], lane, rgbc, sigc);
+    if (p.coarse_sigma) p.coarse_sigma[ray * NS + lane] = sigc;
+
+    // ---- coarse ray-march weights (63 intervals: lane i <-> samples i, i+1)
+    const float zn = __shfl_down(zc, 1, 64), sn = __shfl_down(sigc, 1, 64);
+    float wgt;
+    {
+      const float dl = zn - zc;
+      const float dm = softplus20((sigc + sn) * 0.5f - 1.0f);
+      float alpha = 1.0f - expf(-(dm * dl));
+      if (lane == NS - 1) alpha = 0.f;
+      const float T = wave_excl_prod(lane == NS - 1 ? 1.0f : (1.0f - alpha + 1e-10f), lane);
+      wgt = alpha * T;                                       // lane 63: 0 (unused)
+    }
+    // ---- importance sampling (renderer.py:479-552)
+    float zf;
+    {
+      const float wm1 = __shfl_up(wgt, 1, 64);
+      // max_pool1d(k=2,s=1,pad=1) over 63 weights -> 64 values
+      const float mp = lane == 0 ? wgt : (lane == NS - 1 ? wm1 : fmaxf(wm1, wgt));
+      const float mpn = __shfl_down(mp, 1, 64);
+      const float av = (mp + mpn) * 0.5f + 0.01f;           // avg_pool1d(2,1): 63 values (lanes 0..62)
+      // pdf over weights[1:-1]  -> 61 values; lane k (0..60) takes av[k+1]
+      const float wk = __shfl_down(av, 1, 64) + 1e-5f;
+      const float wv = lane < NS - 3 ? wk : 0.f;
+      const float tot = wave_sum(wv);
+      const float pdf = wv / tot;
+      const float cdf_incl = wave_incl_sum(pdf, lane);
+      const float cdf_excl = __shfl_up(cdf_incl, 1, 64);
+      const float cdf = lane == 0 ? 0.f : cdf_excl;          // cdf[k], k = 0..61 valid
+      const float zmid = 0.5f * (zc + zn);                  // bins[k], k = 0..62 valid
+      float* cdf_s = feat; float* bin_s = feat + 64;
+      cdf_s[lane] = lane <= NS - 3 ? cdf : 3.0e38f;
+      bin_s[lane] = zmid;
+      wave_sync();
+      const float u = p.u_fine[ray * NS + lane];
+      // searchsorted(cdf[0..61], u, right=True) = #entries <= u
+      int lo = 0, hi = NS - 2;                               // 62 entries
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const bool le = lo < hi && cdf_s[mid] <= u;
+        lo = le ? mid + 1 : lo;
+        hi = (lo < hi && !le) ? mid : hi;
+      }
+      const int inds = lo;
+      const int below = inds - 1 < 0 ? 0 : inds - 1;
+      const int above = inds > NS - 3 ? NS - 3 : inds;       // clamp_max(N_samples_=61)
+      const float cb = cdf_s[below], ca = cdf_s[above], bb = bin_s[below], ba = bin_s[above];
+      float den = ca - cb;
+      den = den < 1e-5f ? 1.0f : den;
+      zf = bb + (u - cb) / den * (ba - bb);
+      wave_sync();
+    }
+    if (p.fine_depths) p.fine_depths[ray * NS + lane] = zf;
+    float rgbf[3], sigf;
+    shade64(p, planes, feat, dec, o[0] + zf * d[0], o[1] + zf * d[1], o[2] + zf * d[2], lane, rgbf, sigf);
+
+    // ---- merge coarse + fine by rank (replaces cat + torch.sort + gathers)
+    float* zc_s = feat; float* zf_s = feat + 64; float* srt = feat + 128;   // srt: 128 x {z, sigma, r, g, b}
+    zc_s[lane] = zc; zf_s[lane] = zf;
+    wave_sync();
+    int rc = lane, rf = 0;
+#pragma unroll 4
+    for (int k = 0; k < NS; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
+      const float4 b = *reinterpret_cast<const float4*>(zc_s + k);
+      rc += (a.x < zc) + (a.y < zc) + (a.z < zc) + (a.w < zc);
+      rf += (b.x <= zf) + (b.y <= zf) + (b.z <= zf) + (b.w <= zf);
+      rf += (a.x < zf || (a.x == zf && k + 0 < lane)) + (a.y < zf || (a.y == zf && k + 1 < lane)) +
+            (a.z < zf || (a.z == zf && k + 2 < lane)) + (a.w < zf || (a.w == zf && k + 3 < lane));
+    }
+    // coarse depths are non-decreasing in lane but equal neighbours would collide: break ties by lane
+    // (z_i == z_j for i<j only if jitter/delta degenerate; ranks stay a permutation because rc counts
+    //  strictly-smaller fine + own index, rf counts coarse <= zf)
+    srt[rc * 5 + 0] = zc; srt[rc * 5 + 1] = sigc; srt[rc * 5 + 2] = rgbc[0]; srt[rc * 5 + 3] = rgbc[1]; srt[rc * 5 + 4] = rgbc[2];
+    srt[rf * 5 + 0] = zf; srt[rf * 5 + 1] = sigf; srt[rf * 5 + 2] = rgbf[0]; srt[rf * 5 + 3] = rgbf[1]; srt[rf * 5 + 4] = rgbf[2];
+    wave_sync();
+    // lane i: elements 2i, 2i+1, 2i+2 -> intervals 2i and 2i+1 (interval 127 does not exist)
+    float e[3][5];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = 2 * lane + q < 2 * NS ? 2 * lane + q : 2 * NS - 1;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) e[q][c] = srt[idx * 5 + c];
+    }
+    wave_sync();
+    float a0, a1;
+    {
+      const float dm0 = softplus20((e[0][1] + e[1][1]) * 0.5f - 1.0f);
+      a0 = 1.0f - expf(-(dm0 * (e[1][0] - e[0][0])));
+      const float dm1 = softplus20((e[1][1] + e[2][1]) * 0.5f - 1.0f);
+      a1 = lane == NS - 1 ? 0.f : 1.0f - expf(-(dm1 * (e[2][0] - e[1][0])));
+    }
+    const float f0 = 1.0f - a0 + 1e-10f, f1 = lane == NS - 1 ? 1.0f : (1.0f - a1 + 1e-10f);
+    const float Ts = wave_excl_prod(f0 * f1, lane);
+    const float w0 = a0 * Ts, w1 = a1 * (Ts * f0);
+    float acc_r = w0 * (e[0][2] + e[1][2]) * 0.5f + w1 * (e[1][2] + e[2][2]) * 0.5f;
+    float acc_g = w0 * (e[0][3] + e[1][3]) * 0.5f + w1 * (e[1][3] + e[2][3]) * 0.5f;
+    float acc_b = w0 * (e[0][4] + e[1][4]) * 0.5f + w1 * (e[1][4] + e[2][4]) * 0.5f;
+    float acc_d = w0 * (e[0][0] + e[1][0]) * 0.5f + w1 * (e[1][0] + e[2][0]) * 0.5f;
+    float acc_w = w0 + w1;
+    acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
+    acc_d = wave_sum(acc_d); acc_w = wave_sum(acc_w);
+    dmin_l = fminf(dmin_l, fminf(zc, zf)); dmax_l = fmaxf(dmax_l, fmaxf(zc, zf));
+    if (lane == 0) {
+      if (p.white_back) { acc_r += 1.0f - acc_w; acc_g += 1.0f - acc_w; acc_b += 1.0f - acc_w; }
+      const int64_t img = (int64_t)v * 3 * M;
+      p.rgb[img + pix] = acc_r * 2.0f - 1.0f;
+      p.rgb[img + M + pix] = acc_g * 2.0f - 1.0f;
+      p.rgb[img + 2 * M + pix] = acc_b * 2.0f - 1.0f;
+      p.depth[ray] = acc_d;          // clamped by render_finalize_kernel
+      p.wsum[ray] = acc_w;
+    }
+  }
+  dmin_l = wave_min(dmin_l); dmax_l = wave_max(dmax_l);
+  if (lane == 0 && dmin_l <= dmax_l) {
+    atomicMin(&p.scal_u[2], enc_f(dmin_l));
+    atomicMax(&p.scal_u[3], enc_f(dmax_l));
+  }
+}
+
+// depth = clamp(nan_to_num(depth, inf), min(all depths), max(all depths))   (ray_marcher.py:57-61)
+__global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lo = dec_f(scal_u[2]), hi = dec_f(scal_u[3]);
+  float dv = depth[i];
+  if (dv != dv) dv = INFINITY;
+  depth[i] = fminf(fmaxf(dv, lo), hi);
+}
+
+extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
+  if (!a || !a->planes || !a->plane_index || !a->cams || !a->jitter || !a->u_fine || !a->rgb || !a->depth || !a->wsum ||
+      !a->ray_limits || !a->scalars || !a->dec_w0 || !a->dec_b0 || !a->dec_w1 || !a->dec_b1)
+    return LN3D_ERR_BAD_ARG;
+  if (a->V <= 0 || a->res <= 0) return LN3D_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  RenderP p;
+  p.planes = a->planes; p.H = a->H; p.W = a->W; p.plane_index = a->plane_index; p.cams = a->cams; p.V = a->V; p.res = a->res;
+  p.jitter = a->jitter; p.u_fine = a->u_fine;
+  p.coord_scale = (float)(2.0 / (double)a->box_warp); p.bbox_min = a->bbox_min; p.bbox_max = a->bbox_max; p.white_back = a->white_back;
+  p.rgb = a->rgb; p.depth = a->depth; p.wsum = a->wsum; p.ray_limits = a->ray_limits;
+  p.scal_u = reinterpret_cast<uint32_t*>(a->scalars); p.dec = a->scalars + DEC_OFF;
+  p.coarse_sigma = a->coarse_sigma; p.fine_depths = a->fine_depths;
+  const int64_t nrays = (int64_t)a->V * a->res * a->res;
+  hipLaunchKernelGGL(render_init_kernel, dim3(4), dim3(256), 0, s, p.scal_u, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
+  hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
+  int64_t blocks = (nrays + 3) / 4;
+  const int64_t cap = 256 * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 4 * WAVE_LDS_FLOATS * sizeof(float), s, p, p.dec);
+  hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ point query (sigma / rgb grid), no bbox filter
+__global__ __launch_bounds__(256) void query_points_kernel(RenderP p, const float* __restrict__ dec, const float* pts, int64_t P, float* sigma, float* rgb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* feat = lds + wid * WAVE_LDS_FLOATS;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int64_t ngroups = (P + 63) / 64;
+  for (int64_t gidx = (int64_t)blockIdx.x * 4 + wid; gidx < ngroups; gidx += nw) {
+    int64_t i = gidx * 64 + lane;
+    const bool ok = i < P;
+    if (!ok) i = P - 1;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    float c[3], sg;
+    shade64(p, p.planes, feat, dec, x, y, z, lane, c, sg);
+    if (ok) { sigma[i] = sg; rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2]; }
+  }
+}
+
+// dec scratch for query: caller passes packed decoder via the same init kernel into a static device buffer
+static float* g_query_dec = nullptr;
+
+extern "C" int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P, const float* dec_w0,
+                                 const float* dec_b0, const float* dec_w1, const float* dec_b1, float box_warp, float* sigma,
+                                 float* rgb, void* stream) {
+  if (!planes || !points || !sigma || !rgb || P <= 0) return LN3D_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!g_query_dec) {
+    if (hipMalloc(&g_query_dec, (DEC_OFF + DEC_FLOATS) * sizeof(float)) != hipSuccess) return LN3D_ERR_LAUNCH;
+  }
+  RenderP p{};
+  p.planes = planes; p.H = H; p.W = W; p.coord_scale = (float)(2.0 / (double)box_warp);
+  p.bbox_min = -3.0e38f; p.bbox_max = 3.0e38f;
+  p.scal_u = reinterpret_cast<uint32_t*>(g_query_dec); p.dec = g_query_dec + DEC_OFF;
+  hipLaunchKernelGGL(render_init_kernel, dim3(4), dim3(256), 0, s, p.scal_u, g_query_dec + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
+  int64_t blocks = ((P + 63) / 64 + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)blocks), dim3(256), 4 * WAVE_LDS_FLOATS * sizeof(float), s, p, p.dec, points, P, sigma, rgb);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ [NP, 3*C, H, W] -> [NP, 3, H, W, C]
+__global__ void planes_to_cl_kernel(const float* src, float* dst, int C, int HW, int64_t total) {
+  // one thread per (np*3 + n, hw, c): read src[(pn*C + c)*HW + hw] -> dst[(pn*HW + hw)*C + c]
+  __shared__ float tile[32][33];
+  const int pn = blockIdx.y;
+  const int hw0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int c = ty; c < C; c += 8) {
+    const int hw = hw0 + tx;
+    tile[c][tx] = hw < HW ? src[((int64_t)pn * C + c) * HW + hw] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int hw = hw0 + r;
+    if (hw < HW && tx < C) dst[((int64_t)pn * HW + hw) * C + tx] = tile[tx][r];
+  }
+}
+extern "C" int ln3d_planes_to_channel_last(const float* src, float* dst, int NP, int C, int H, int W, void* stream) {
+  if (!src || !dst || C != 32) return LN3D_ERR_BAD_ARG;
+  const int HW = H * W;
+  hipLaunchKernelGGL(planes_to_cl_kernel, dim3((HW + 31) / 32, NP * 3), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, (int64_t)NP * 3 * C * HW);
+  return ln3d_check_launch();
+}

@@ -1,0 +1,258 @@
+"""DiT_TriLatent (text -> tri-plane latent denoiser) on the HIP kernels.
+
+Same constructor / forward surface and state-dict keys as the reference's
+dit/dit_trilatent.py:22-143 (`DiT_models[arch](input_size, num_classes, learn_sigma, in_channels,
+context_dim, roll_out, vit_blk)`, `forward(x, timesteps, context, y=None, get_attr='', **kw)`
+returning float32 [B, C*3, H, W]); the forward pass is a fixed sequence of HIP launches:
+
+  per forward : timestep sin/cos -> 2 GEMMs (SiLU fused) -> ONE GEMM for every block's adaLN (depth*6D+2D cols)
+                caption MLP (2 GEMMs, tanh-GELU fused) -> per-block K/V^T of the context (cacheable per prompt)
+                patch-embed(+pos-embed, + optional EDM c_in scale)
+  per block   : LN+modulate -> QKV GEMM (head-split epilogue, V^T emitted) -> fused attention ->
+                proj GEMM (gate*out + residual epilogue, bf16 copy of x) -> to_q GEMM -> fused cross
+                attention -> to_out GEMM (residual epilogue) -> LN+modulate -> fc1 GEMM (erf-GELU epilogue)
+                -> fc2 GEMM (gate*out + residual epilogue)
+  final       : LN+modulate+Linear(D->p*p*C)+unpatchify in one kernel.
+The residual stream, LN statistics, softmax and all accumulators are fp32; GEMM operands are bf16.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .dit_models_xformers import (CaptionEmbedder, DiTBlock, FinalLayer, PatchEmbed, T2IFinalLayer,  # noqa: F401
+                                  TextCondDiTBlock, TimestepEmbedder, Workspace, bf16, f32,
+                                  get_2d_sincos_pos_embed, self_attention_hip)
+
+
+class DiT(nn.Module):
+    """Base container (reference dit/dit_models_xformers.py:681-835)."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, num_classes=1000, learn_sigma=True, mixing_logit_init=-3,
+                 mixed_prediction=True, context_dim=False, roll_out=False, vit_blk=DiTBlock,
+                 final_layer_blk=FinalLayer):
+        super().__init__()
+        self.plane_n = 3
+        self.depth, self.mlp_ratio, self.learn_sigma = depth, mlp_ratio, learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.patch_size, self.num_heads, self.embed_dim = patch_size, num_heads, hidden_size
+        self.input_size = input_size
+        self.roll_out = roll_out
+        self.x_embedder = PatchEmbed(input_size, patch_size, in_channels, hidden_size, bias=True)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.y_embedder = None
+        self.clip_text_proj = CaptionEmbedder(context_dim, hidden_size) if context_dim is not None else None
+        self.context_dim = context_dim
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.x_embedder.num_patches, hidden_size), requires_grad=False)
+        self.blocks = nn.ModuleList([vit_blk(hidden_size=hidden_size, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                                             context_dim=context_dim) for _ in range(depth)])
+        self.final_layer = final_layer_blk(hidden_size, patch_size, self.out_channels)
+        self.initialize_weights()
+        self._packed = None
+        self._ws = None
+
+    def initialize_weights(self):
+        # same rules as the reference (:777-819); sampling uses loaded / synthetic weights anyway
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for blk in self.blocks:
+            if getattr(blk, 'adaLN_modulation', None) is not None:
+                nn.init.constant_(blk.adaLN_modulation[-1].weight, 0)
+                nn.init.constant_(blk.adaLN_modulation[-1].bias, 0)
+        if getattr(self.final_layer, 'adaLN_modulation', None) is not None:
+            nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    # any parameter change invalidates the packed device copies
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def flat_weights(self):
+        """All packed device tensors (for the one-buffer RCCL broadcast in ln3diff_amd.parallel)."""
+        self._ensure_packed(next(self.parameters()).device)
+        out = []
+
+        def walk(o):
+            if isinstance(o, torch.Tensor):
+                out.append(o)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        walk(self._packed)
+        return out
+
+
+class DiT_TriLatent(DiT):
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4, class_dropout_prob=0.1, num_classes=1000, learn_sigma=True, mixing_logit_init=-3,
+                 mixed_prediction=True, context_dim=False, roll_out=False, vit_blk=DiTBlock,
+                 final_layer_blk=FinalLayer):
+        super().__init__(input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio,
+                         class_dropout_prob, num_classes, learn_sigma, mixing_logit_init, mixed_prediction,
+                         context_dim, roll_out, vit_blk, final_layer_blk)
+        assert self.roll_out
+        self.init_PE_3D_aware()
+
+    def init_PE_3D_aware(self):
+        L = self.x_embedder.num_patches
+        D = self.embed_dim
+        pe = get_2d_sincos_pos_embed(D, (self.plane_n, L)).reshape(self.plane_n * L, D)
+        self.pos_embed = nn.Parameter(torch.from_numpy(pe).float().unsqueeze(0), requires_grad=False)
+
+    # ------------------------------------------------------------------ packing
+    def _ensure_packed(self, device):
+        if self._packed is not None and self._packed['device'] == device:
+            return
+        D = self.embed_dim
+        P = {'device': device}
+        P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
+        P['pe_b'] = f32(self.x_embedder.proj.bias, device)
+        P['pos'] = f32(self.pos_embed[0], device)
+        P['t_w0'], P['t_b0'] = bf16(self.t_embedder.mlp[0].weight, device), f32(self.t_embedder.mlp[0].bias, device)
+        P['t_w2'], P['t_b2'] = bf16(self.t_embedder.mlp[2].weight, device), f32(self.t_embedder.mlp[2].bias, device)
+        cp = self.clip_text_proj.y_proj
+        P['c_w1'], P['c_b1'] = bf16(cp.fc1.weight, device), f32(cp.fc1.bias, device)
+        P['c_w2'], P['c_b2'] = bf16(cp.fc2.weight, device), f32(cp.fc2.bias, device)
+        ada_w = [b.adaLN_modulation[1].weight for b in self.blocks] + [self.final_layer.adaLN_modulation[1].weight]
+        ada_b = [b.adaLN_modulation[1].bias for b in self.blocks] + [self.final_layer.adaLN_modulation[1].bias]
+        P['ada_w'], P['ada_b'] = bf16(torch.cat(ada_w, 0), device), f32(torch.cat(ada_b, 0), device)
+        blks = []
+        for b in self.blocks:
+            q = {}
+            q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
+            q['proj_w'], q['proj_b'] = bf16(b.attn.proj.weight, device), f32(b.attn.proj.bias, device)
+            q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
+            q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
+            q['co_w'], q['co_b'] = bf16(b.cross_attn.to_out[0].weight, device), f32(b.cross_attn.to_out[0].bias, device)
+            q['fc1_w'], q['fc1_b'] = bf16(b.mlp.mlp[0].weight, device), f32(b.mlp.mlp[1].bias, device)
+            q['fc2_w'], q['fc2_b'] = bf16(b.mlp.mlp[2].weight, device), f32(b.mlp.mlp[3].bias, device)
+            blks.append(q)
+        P['blocks'] = blks
+        P['fin_w'], P['fin_b'] = f32(self.final_layer.linear.weight, device), f32(self.final_layer.linear.bias, device)
+        self._packed = P
+        self._ws = Workspace(device)
+
+    # ------------------------------------------------------------------ context (constant per prompt)
+    def prepare_context(self, context):
+        """clip_text_proj + every block's cross-attention K / V^T.  They depend only on the prompt, so the
+        samplers call this once per run instead of once per step (the reference recomputes them 250x)."""
+        if isinstance(context, dict):
+            context = context['crossattn']
+        dev = context.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        Bn, Lc, Cd = context.shape
+        D, H = self.embed_dim, self.num_heads
+        lpad = (Lc + 63) // 64 * 64
+        cb = ws.get('ctx_bf', (Bn * Lc, Cd), torch.bfloat16)
+        ops.cast_bf16(context.contiguous().float(), cb)
+        h1 = ws.get('ctx_h1', (Bn * Lc, D), torch.bfloat16)
+        ops.gemm(cb, P['c_w1'], P['c_b1'], ops.EPI_GELU_TANH, h1)
+        cp = ws.get('ctx_p', (Bn * Lc, D), torch.bfloat16)
+        ops.gemm(h1, P['c_w2'], P['c_b2'], ops.EPI_BF16, cp)
+        dh = 64
+        k_all = torch.zeros(self.depth, Bn, H, lpad, dh, dtype=torch.bfloat16, device=dev)
+        vt_all = torch.zeros(self.depth, Bn, H, dh, lpad, dtype=torch.bfloat16, device=dev)
+        for i, q in enumerate(P['blocks']):
+            ops.gemm(cp, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad,
+                     heads=H, head_dim=dh, transpose_mask=0b10)
+        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn}
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None,
+                **kwargs):
+        if get_attr != '':
+            return getattr(self, get_attr)
+        assert context is not None or context_cache is not None
+        if not x.is_cuda:
+            raise RuntimeError("ln3diff_amd.DiT_TriLatent runs on the HIP device only (no CPU fallback)")
+        dev = x.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        D, H, depth = self.embed_dim, self.num_heads, self.depth
+        Bn = timesteps.shape[0]
+        Bx = x.shape[0]
+        S, p, C = self.input_size, self.patch_size, self.in_channels
+        L = (S // p) ** 2
+        N = 3 * L
+        M = Bn * N
+        cc = context_cache if context_cache is not None else self.prepare_context(context)
+        assert cc['Bn'] == Bn
+
+        # -- timestep embedding and all adaLN modulations
+        t32 = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        tf = ws.get('tfreq', (Bn, 256), torch.bfloat16)
+        ops.timestep_embedding(t32, tf, Bn, 256)
+        th = ws.get('th', (Bn, D), torch.bfloat16)
+        ops.gemm(tf, P['t_w0'], P['t_b0'], ops.EPI_SILU, th)
+        temb = ws.get('temb', (Bn, D), torch.float32)
+        tsilu = ws.get('tsilu', (Bn, D), torch.bfloat16)
+        ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32_SILU, temb, tsilu)
+        nmod = depth * 6 * D + 2 * D
+        mod = ws.get('mod', (Bn, nmod), torch.float32)
+        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
+
+        # -- tokens
+        xt = ws.get('x', (M, D), torch.float32)
+        ops.patch_embed(x.contiguous().float(), in_scale, P['pe_w'], P['pe_b'], P['pos'], xt, Bx, Bn, C, S, p, D)
+        hb = ws.get('h', (M, D), torch.bfloat16)
+        xb = ws.get('xb', (M, D), torch.bfloat16)
+        qc = ws.get('qc', (Bn, H, N, 64), torch.bfloat16)
+        oc = ws.get('oc', (M, H * 64), torch.bfloat16)
+        f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
+
+        for i, q in enumerate(P['blocks']):
+            o6 = i * 6 * D
+            sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
+            sh_m, sc_m, g_m = mod[:, o6 + 3 * D:], mod[:, o6 + 4 * D:], mod[:, o6 + 5 * D:]
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=nmod)
+            ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
+            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=nmod)
+            # cross attention on x (no pre-norm, no gate; reference :318)
+            ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
+            ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
+            ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=nmod)
+            ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+            ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=nmod)
+
+        of = depth * 6 * D
+        out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)
+        ops.final_layer(xt, mod[:, of:], mod[:, of + D:], nmod, None, None, P['fin_w'], P['fin_b'], out, Bn,
+                        self.out_channels, S, p, D)
+        return out
+
+
+def DiT_XL_2(**kwargs):
+    return DiT_TriLatent(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_L_2(**kwargs):
+    return DiT_TriLatent(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_B_2(**kwargs):
+    return DiT_TriLatent(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
+
+
+DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2}

@@ -1,0 +1,141 @@
+"""Triplane renderer module on the fused HIP ray-marcher.
+
+Mirrors the reference's nsr/triplane.py `Triplane` (forward(planes, c) -> dict with image_raw,
+image_depth, weights_samples, image_mask, ...) and `OSGDecoder` (state-dict keys
+`decoder.net.{0,2}.{weight,bias}`) for the Objaverse rendering preset
+(nsr/script_util.py:761-798: 64 + 64 samples, box_warp 0.9, bbox +-0.45, white background,
+auto ray limits).  ray generation, sampling, gather, MLP and compositing all run inside
+`ln3d_render_triplane` (csrc/render.hip) - nothing of the reference's [V,3,M*S,32] feature tensor
+or its sort/gather intermediates is ever materialised.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import RENDER_SCRATCH_FLOATS
+
+
+class FullyConnectedLayer(nn.Module):      # nsr/networks_stylegan2.py:122-157 (container; gain applied in-kernel)
+    def __init__(self, in_features, out_features, lr_multiplier=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = nn.Parameter(torch.zeros([out_features]))
+
+
+class OSGDecoder(nn.Module):               # nsr/triplane.py:339-372
+    def __init__(self, n_features=32, options=None):
+        super().__init__()
+        options = options or {'decoder_lr_mul': 1, 'decoder_output_dim': 3}
+        assert options.get('decoder_lr_mul', 1) == 1
+        self.hidden_dim = 64
+        self.decoder_output_dim = options['decoder_output_dim']
+        assert n_features == 32 and self.decoder_output_dim == 3, "HIP renderer is built for the released 32->64->4 decoder"
+        self.net = nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim), nn.Softplus(),
+                                 FullyConnectedLayer(self.hidden_dim, 1 + self.decoder_output_dim))
+
+
+OBJAVERSE_RENDERING_KWARGS = dict(
+    depth_resolution=64, depth_resolution_importance=64, ray_start='auto', ray_end='auto', box_warp=0.9,
+    white_back=True, sampler_bbox_min=-0.45, sampler_bbox_max=0.45, filter_out_of_bbox=True,
+    clamp_mode='softplus', disparity_space_sampling=False, PatchRaySampler=True, decoder_lr_mul=1)
+
+
+def draw_render_noise(V, M, S=64, generator=None, device='cpu'):
+    """The reference's RNG consumption per Triplane.forward, as logical tensors:
+    coarse jitter = rand_like on a [S,V,M,1]-strided tensor, then fine uniforms rand(V*M, S)."""
+    if device == 'cpu' or str(device) == 'cpu':
+        j = torch.rand(S, V, M, 1, generator=generator).permute(1, 2, 0, 3).reshape(V, M, S).contiguous()
+        u = torch.rand(V * M, S, generator=generator)
+    else:
+        j = torch.rand(V, M, S, device=device, generator=generator)
+        u = torch.rand(V * M, S, device=device, generator=generator)
+    return j, u
+
+
+class Triplane(nn.Module):
+    def __init__(self, c_dim=25, img_resolution=128, img_channels=3, out_chans=96, triplane_size=224,
+                 rendering_kwargs=None, decoder_in_chans=32, decoder_output_dim=3, **_):
+        super().__init__()
+        self.rendering_kwargs = dict(OBJAVERSE_RENDERING_KWARGS if rendering_kwargs is None else rendering_kwargs)
+        rk = self.rendering_kwargs
+        assert rk['depth_resolution'] == 64 and rk['depth_resolution_importance'] == 64
+        assert rk['ray_start'] == rk['ray_end'] == 'auto' and rk.get('filter_out_of_bbox', False)
+        self.neural_rendering_resolution = img_resolution
+        self.decoder_in_chans = decoder_in_chans
+        self.decoder = OSGDecoder(decoder_in_chans, {'decoder_lr_mul': 1, 'decoder_output_dim': decoder_output_dim})
+        self._dec = None
+
+    def _apply(self, fn, *a, **k):
+        self._dec = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._dec = None
+        return super().load_state_dict(*a, **k)
+
+    def _decoder_dev(self, dev):
+        if self._dec is None or self._dec[0].device != dev:
+            n = self.decoder.net
+            self._dec = tuple(t.detach().to(dev, torch.float32).contiguous()
+                              for t in (n[0].weight, n[0].bias, n[2].weight, n[2].bias))
+        return self._dec
+
+    @staticmethod
+    def to_channel_last(planes):
+        """[NP, 96, H, W] (reference '(n c) h w') -> [NP, 3, H, W, 32] f32 for the gather kernel."""
+        NP, C3, H, W = planes.shape
+        out = torch.empty(NP, 3, H, W, C3 // 3, device=planes.device, dtype=torch.float32)
+        ops.planes_to_channel_last(planes.contiguous().float(), out, NP, C3 // 3, H, W)
+        return out
+
+    @torch.no_grad()
+    def forward(self, planes=None, c=None, neural_rendering_resolution=None, jitter=None, u_fine=None,
+                planes_channel_last=None, plane_index=None, return_debug=False, **_):
+        """planes [V,96,H,W] (one tri-plane per camera row, as the reference) or
+        planes_channel_last [NP,3,H,W,32] + plane_index [V] (many views of few tri-planes)."""
+        res = neural_rendering_resolution or self.neural_rendering_resolution
+        self.neural_rendering_resolution = res
+        if not c.is_cuda:
+            raise RuntimeError("ln3diff_amd.Triplane runs on the HIP device only (no CPU fallback)")
+        dev = c.device
+        V, M, S = c.shape[0], res * res, 64
+        if planes_channel_last is None:
+            planes_channel_last = self.to_channel_last(planes)
+            plane_index = torch.arange(V, device=dev, dtype=torch.int32)
+        H, W = planes_channel_last.shape[2], planes_channel_last.shape[3]
+        if jitter is None:
+            jitter, u_fine = draw_render_noise(V, M, S, device=dev)
+        jitter = jitter.to(dev, torch.float32).reshape(V, M, S).contiguous()
+        u_fine = u_fine.to(dev, torch.float32).reshape(V * M, S).contiguous()
+        rk = self.rendering_kwargs
+        rgb = torch.empty(V, 3, res, res, device=dev)
+        depth = torch.empty(V, 1, res, res, device=dev)
+        wsum = torch.empty(V, 1, res, res, device=dev)
+        lim = torch.empty(V * M * 2, device=dev)
+        scal = torch.empty(RENDER_SCRATCH_FLOATS, device=dev)
+        cs = torch.empty(V, M, S, device=dev) if return_debug else None
+        fd = torch.empty(V, M, S, device=dev) if return_debug else None
+        ops.render_triplane(planes_channel_last, H, W, plane_index.to(dev, torch.int32).contiguous(),
+                            c.to(torch.float32).contiguous(), res, self._decoder_dev(dev), jitter, u_fine, rgb, depth,
+                            wsum, lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
+                            bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=cs,
+                            fine_depths=fd)
+        ret = {'feature_image': rgb, 'image_raw': rgb, 'image_depth': depth, 'weights_samples': wsum,
+               'image_mask': wsum * (1 + 2 * 0.001) - 0.001,
+               'shape_synthesized': {'image_depth': depth}}
+        if return_debug:
+            ret['shape_synthesized'].update(coarse_densities=cs.unsqueeze(-1), fine_depths=fd.unsqueeze(-1))
+        return ret
+
+    @torch.no_grad()
+    def query_points(self, planes_channel_last_one, points):
+        """points [P,3] against ONE tri-plane [3,H,W,32] -> {'sigma':[P,1],'rgb':[P,3]} (no bbox filter:
+        renderer._run_model as used by forward_points, vit/vit_triplane.py:2026-2041)."""
+        dev = points.device
+        P = points.shape[0]
+        H, W = planes_channel_last_one.shape[-3], planes_channel_last_one.shape[-2]
+        sigma = torch.empty(P, 1, device=dev)
+        rgb = torch.empty(P, 3, device=dev)
+        ops.query_points(planes_channel_last_one.contiguous(), H, W, points.contiguous().float(), self._decoder_dev(dev),
+                         self.rendering_kwargs['box_warp'], sigma, rgb)
+        return {'sigma': sigma, 'rgb': rgb}

@@ -1,0 +1,142 @@
+"""Thin torch-tensor wrappers over the C ABI (include/ln3d.h).  torch is used for device
+memory and streams only; every op below is a HIP kernel launch on torch's current stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES,  # noqa: F401
+                   EPI_HEADS, EPI_F32_SILU)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ln3diff_amd ops need device tensors (no CPU fallback exists)")
+
+
+def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, gate=None, gate_rows=1,
+         gate_ld=0, tokens=0, tok_pad=0, heads=0, head_dim=0, transpose_mask=0):
+    """out = epi(x[M,K] @ w[N,K]^T + bias).  x, w bf16 (row stride = shape[-1])."""
+    _chk_dev(x, w, out0)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    a = L.GemmArgs()
+    K = w.shape[1]
+    a.X, a.ldx, a.W, a.ldw = _p(x), x.stride(-2) if x.dim() > 1 else K, _p(w), w.stride(0)
+    a.bias = _p(bias)
+    a.M = int(M if M is not None else x.numel() // K)
+    a.N, a.K = w.shape[0], K
+    a.epilogue = epilogue
+    a.out0, a.out1, a.out2 = _p(out0), _p(out1), _p(out2)
+    a.ldo = int(ldo if ldo is not None else w.shape[0])
+    a.gate, a.gate_rows, a.gate_ld = _p(gate), gate_rows, gate_ld
+    a.tokens, a.tok_pad, a.heads, a.head_dim, a.transpose_mask = tokens, tok_pad, heads, head_dim, transpose_mask
+    L.check(L.lib().ln3d_gemm_bf16(C.byref(a), _stream()), "gemm")
+
+
+def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None):
+    _chk_dev(q, k, vt, out)
+    a = L.AttnArgs()
+    a.Q, a.K, a.Vt, a.O = _p(q), _p(k), _p(vt), _p(out)
+    a.B, a.H, a.Nq, a.Nq_pad, a.Nk, a.Nk_pad, a.Dh = B, H, Nq, Nq_pad, Nk, Nk_pad, Dh
+    a.ldo = H * Dh
+    a.scale = float(scale if scale is not None else Dh ** -0.5)
+    L.check(L.lib().ln3d_attention_bf16(C.byref(a), _stream()), "attention")
+
+
+def rmsnorm_heads(x, w, rows, Dh, eps=1e-5):
+    L.check(L.lib().ln3d_rmsnorm_heads_bf16(_p(x), _p(w), C.c_int64(rows), Dh, C.c_float(eps), _stream()), "rmsnorm_heads")
+
+
+def norm_modulate(x, y, rows, D, kind=0, eps=1e-6, weight=None, shift=None, scale=None, mod_rows=1, mod_ld=0,
+                  shift_table=None, scale_table=None, rows_in=0, rows_out=0):
+    _chk_dev(x, y)
+    a = L.NormArgs()
+    a.x, a.y, a.rows, a.D, a.kind, a.eps, a.weight = _p(x), _p(y), rows, D, kind, eps, _p(weight)
+    a.shift, a.scale, a.mod_rows, a.mod_ld = _p(shift), _p(scale), mod_rows, mod_ld
+    a.shift_table, a.scale_table, a.rows_in, a.rows_out = _p(shift_table), _p(scale_table), rows_in, rows_out
+    L.check(L.lib().ln3d_norm_modulate(C.byref(a), _stream()), "norm_modulate")
+
+
+def timestep_embedding(t, out, B, dim=256):
+    L.check(L.lib().ln3d_timestep_embedding(_p(t), _p(out), B, dim, _stream()), "timestep_embedding")
+
+
+def add_act_cast(a, b, y_bf16, sum_f32, n, act):
+    L.check(L.lib().ln3d_add_act_cast(_p(a), _p(b), _p(y_bf16), _p(sum_f32), C.c_int64(n), act, _stream()), "add_act_cast")
+
+
+def cast_bf16(x, y):
+    L.check(L.lib().ln3d_cast_f32_bf16(_p(x), _p(y), C.c_int64(x.numel()), _stream()), "cast")
+
+
+def patch_embed(x, in_scale, w, bias, pos, tokens, Bx, Bn, Cc, S, p, D):
+    L.check(L.lib().ln3d_patch_embed(_p(x), _p(in_scale), _p(w), _p(bias), _p(pos), _p(tokens), Bx, Bn, Cc, S, p, D, _stream()),
+            "patch_embed")
+
+
+def final_layer(tokens, shift, scale, mod_ld, shift_table, scale_table, w, bias, out, Bn, Cc, S, p, D):
+    L.check(L.lib().ln3d_final_layer(_p(tokens), _p(shift), _p(scale), C.c_int64(mod_ld), _p(shift_table), _p(scale_table),
+                                     _p(w), _p(bias), _p(out), Bn, Cc, S, p, D, _stream()), "final_layer")
+
+
+def edm_euler_step(x, eps2, sigma, sigma_next, cfg_scale):
+    L.check(L.lib().ln3d_edm_euler_step(_p(x), _p(eps2), C.c_float(sigma), C.c_float(sigma_next), C.c_float(cfg_scale),
+                                        C.c_int64(x.numel()), _stream()), "edm_euler_step")
+
+
+def ddpm_step(x, eps, noise, a, b, c1, c2, sig, clip):
+    L.check(L.lib().ln3d_ddpm_step(_p(x), _p(eps), _p(noise), C.c_float(a), C.c_float(b), C.c_float(c1), C.c_float(c2),
+                                   C.c_float(sig), int(clip), C.c_int64(x.numel()), _stream()), "ddpm_step")
+
+
+def flow_euler_step(x2, v2, dt, cfg_scale):
+    L.check(L.lib().ln3d_flow_euler_step(_p(x2), _p(v2), C.c_float(dt), C.c_float(cfg_scale), C.c_int64(x2.numel() // 2),
+                                         _stream()), "flow_euler_step")
+
+
+def axpby(x, y, a, b):
+    L.check(L.lib().ln3d_axpby(_p(x), _p(y), C.c_float(a), C.c_float(b), C.c_int64(x.numel()), _stream()), "axpby")
+
+
+def planes_to_channel_last(src, dst, NP, Cc, H, W):
+    L.check(L.lib().ln3d_planes_to_channel_last(_p(src), _p(dst), NP, Cc, H, W, _stream()), "planes_to_channel_last")
+
+
+def planes_to_nchw(src, dst, NP, Cc, H, W):
+    L.check(L.lib().ln3d_planes_to_nchw(_p(src), _p(dst), NP, Cc, H, W, _stream()), "planes_to_nchw")
+
+
+def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine, rgb, depth, wsum, ray_limits, scalars,
+                    box_warp=0.9, bbox_min=-0.45, bbox_max=0.45, white_back=True, coarse_sigma=None, fine_depths=None):
+    a = L.RenderArgs()
+    a.planes, a.H, a.W, a.plane_index, a.cams = _p(planes_cl), H, W, _p(plane_index), _p(cams)
+    a.V, a.res = cams.shape[0], res
+    a.dec_w0, a.dec_b0, a.dec_w1, a.dec_b1 = (_p(t) for t in dec)
+    a.jitter, a.u_fine = _p(jitter), _p(u_fine)
+    a.box_warp, a.bbox_min, a.bbox_max, a.white_back = box_warp, bbox_min, bbox_max, int(white_back)
+    a.rgb, a.depth, a.wsum, a.ray_limits, a.scalars = _p(rgb), _p(depth), _p(wsum), _p(ray_limits), _p(scalars)
+    a.coarse_sigma, a.fine_depths = _p(coarse_sigma), _p(fine_depths)
+    L.check(L.lib().ln3d_render_triplane(C.byref(a), _stream()), "render_triplane")
+
+
+def query_points(planes_cl, H, W, points, dec, box_warp, sigma, rgb):
+    L.check(L.lib().ln3d_query_points(_p(planes_cl), H, W, _p(points), C.c_int64(points.shape[0]), *(_p(t) for t in dec),
+                                      C.c_float(box_warp), _p(sigma), _p(rgb), _stream()), "query_points")
+
+
+def groupnorm_swish(x, w, b, y, stats, N, HW, Cc, groups=32, eps=1e-6, swish=True):
+    L.check(L.lib().ln3d_groupnorm_swish(_p(x), _p(w), _p(b), _p(y), _p(stats), N, HW, Cc, groups, C.c_float(eps), int(swish),
+                                         _stream()), "groupnorm_swish")
+
+
+def im2col3x3(x, col, N, H, W, Cc, upsample, Kpad):
+    L.check(L.lib().ln3d_im2col3x3(_p(x), _p(col), N, H, W, Cc, upsample, Kpad, _stream()), "im2col3x3")

@@ -1,0 +1,217 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain torch fp32 / the oracle.
+Tolerances: bf16 GEMM/attention operands -> rel-L2 <= 1e-2 vs an fp32 reference computed from the SAME
+bf16-rounded operands (so the bound measures the kernel, not the rounding of the inputs): <= 2e-3."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    from ln3diff_amd import ops as o
+    return o
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 192), (16, 1024, 256), (1536, 3072, 1024), (77, 512, 768)])
+def test_gemm_plain_epilogues(ops, M, N, K):
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(M + N + K)
+    # ASYMMETRIC operands (transposes must show): x rows scaled by index, w cols scaled
+    x = (torch.randn(M, K, generator=g) * (1 + torch.arange(M)[:, None] / M)).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05 * (1 + torch.arange(K)[None, :] / K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    xb, wb = _bf(x), _bf(w)
+    ref = xb.float() @ wb.float().t() + b
+    out = torch.empty(M, N, device=dev)
+    ops.gemm(xb, wb, b, ops.EPI_F32, out)
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_BF16, o16)
+    assert rel_l2(o16.float(), ref) < 4e-3
+    ops.gemm(xb, wb, b, ops.EPI_GELU_ERF, o16)
+    assert rel_l2(o16.float(), torch.nn.functional.gelu(ref)) < 5e-3
+    ops.gemm(xb, wb, b, ops.EPI_GELU_TANH, o16)
+    assert rel_l2(o16.float(), torch.nn.functional.gelu(ref, approximate='tanh')) < 5e-3
+    ops.gemm(xb, wb, b, ops.EPI_SILU, o16)
+    assert rel_l2(o16.float(), torch.nn.functional.silu(ref)) < 5e-3
+    o32 = torch.empty(M, N, device=dev)
+    ops.gemm(xb, wb, b, ops.EPI_F32_SILU, o32, o16)
+    assert rel_l2(o32, ref) < 2e-5 and rel_l2(o16.float(), torch.nn.functional.silu(ref)) < 5e-3
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I check with an asymmetric B: catches swapped rows/cols in the accumulator write-out."""
+    dev = 'cuda'
+    K = 128
+    x = torch.eye(K, device=dev)                                   # [M=K, K]
+    w = (torch.arange(K * K, device=dev).float().reshape(K, K) % 251) / 64.0   # exactly representable
+    out = torch.empty(K, K, device=dev)
+    ops.gemm(_bf(x), _bf(w), None, ops.EPI_F32, out)
+    assert torch.equal(out, _bf(w).float().t())
+
+
+@pytest.mark.parametrize("rows_per_gate", [1, 96])
+def test_gemm_gate_residual(ops, rows_per_gate):
+    dev = 'cuda'
+    M, N, K = 192, 256, 128
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.1).to(dev), torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ng = M // rows_per_gate
+    gate_full = torch.randn(ng, 3 * N, generator=g).to(dev)       # gate is a column slice of a wider matrix
+    gate = gate_full[:, N:]
+    xb, wb = _bf(x), _bf(w)
+    ref = res + gate[:, :N].repeat_interleave(rows_per_gate, 0) * (xb.float() @ wb.float().t() + b)
+    acc = res.clone()
+    copy = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc, copy, gate=gate, gate_rows=rows_per_gate, gate_ld=3 * N)
+    assert rel_l2(acc, ref) < 2e-5
+    assert rel_l2(copy.float(), ref) < 4e-3
+    acc2 = res.clone()
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc2)
+    assert rel_l2(acc2, res + xb.float() @ wb.float().t() + b) < 2e-5
+
+
+def test_gemm_heads_split(ops):
+    dev = 'cuda'
+    B, T, H, Dh, K = 2, 77, 4, 64, 128
+    tp = 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * T, K, generator=g).to(dev)
+    w = (torch.randn(3 * H * Dh, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(3 * H * Dh, generator=g).to(dev)
+    xb, wb = _bf(x), _bf(w)
+    ref = (xb.float() @ wb.float().t() + b).reshape(B, T, 3, H, Dh)
+    q = torch.zeros(B, H, tp, Dh, device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, Dh, tp, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_HEADS, q, k, vt, M=B * T, tokens=T, tok_pad=tp, heads=H, head_dim=Dh, transpose_mask=0b100)
+    assert rel_l2(q[:, :, :T].float(), ref[:, :, 0].permute(0, 2, 1, 3)) < 4e-3
+    assert rel_l2(k[:, :, :T].float(), ref[:, :, 1].permute(0, 2, 1, 3)) < 4e-3
+    assert rel_l2(vt[:, :, :, :T].float(), ref[:, :, 2].permute(0, 2, 3, 1)) < 4e-3
+    assert float(q[:, :, T:].abs().max()) == 0 and float(vt[:, :, :, T:].abs().max()) == 0
+
+
+def _attn_ref(q, k, v, scale):
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    return torch.softmax(s, -1) @ v.float()
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,Dh", [(2, 2, 768, 768, 64), (1, 3, 768, 77, 64), (2, 2, 256, 256, 64),
+                                           (1, 2, 768, 1024, 64), (3, 1, 256, 256, 128), (1, 1, 100, 130, 64)])
+def test_attention(ops, B, H, Nq, Nk, Dh):
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    nqp, nkp = (Nq + 63) // 64 * 64, (Nk + 63) // 64 * 64
+    q = torch.zeros(B, H, nqp, Dh)
+    k = torch.zeros(B, H, nkp, Dh)
+    v = torch.zeros(B, H, nkp, Dh)
+    q[:, :, :Nq] = torch.randn(B, H, Nq, Dh, generator=g) * 1.5
+    k[:, :, :Nk] = torch.randn(B, H, Nk, Dh, generator=g) * 1.5
+    v[:, :, :Nk] = torch.randn(B, H, Nk, Dh, generator=g) + torch.arange(Dh) / Dh     # asymmetric in d
+    # force the online-softmax rescale: a late key block with a huge score for some query rows
+    if Nk > 128:
+        k[:, :, Nk - 5] = q[:, :, 3] * 4.0
+    qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
+    vt = vb.transpose(-1, -2).contiguous()
+    out = torch.empty(B, Nq, H * Dh, device=dev, dtype=torch.bfloat16)
+    ops.attention(qb, kb, vt, out, B, H, Nq, nqp, Nk, nkp, Dh)
+    ref = _attn_ref(qb[:, :, :Nq], kb[:, :, :Nk], vb[:, :, :Nk], Dh ** -0.5)       # [B,H,Nq,Dh]
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Nq, H * Dh)
+    e = rel_l2(out.float(), ref)
+    assert e < 1e-2, e
+
+
+@pytest.mark.parametrize("D,kind", [(128, 0), (768, 0), (1024, 0), (1152, 0), (1024, 1)])
+def test_norm_modulate(ops, D, kind):
+    dev = 'cuda'
+    B, N = 3, 40
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(B * N, D, generator=g) * 2 + 0.5).to(dev)
+    mod = torch.randn(B, 6 * D, generator=g).to(dev)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    y = torch.empty(B * N, D, device=dev, dtype=torch.bfloat16)
+    sh, sc = mod[:, D:], mod[:, 2 * D:]
+    if kind == 0:
+        ops.norm_modulate(x, y, B * N, D, kind=0, eps=1e-6, shift=sh, scale=sc, mod_rows=N, mod_ld=6 * D)
+        n = torch.nn.functional.layer_norm(x, (D,), eps=1e-6)
+    else:
+        ops.norm_modulate(x, y, B * N, D, kind=1, eps=1e-5, weight=w, shift=sh, scale=sc, mod_rows=N, mod_ld=6 * D)
+        n = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    ref = n * (1 + sc[:, :D].repeat_interleave(N, 0)) + sh[:, :D].repeat_interleave(N, 0)
+    assert rel_l2(y.float(), ref) < 4e-3
+    # row remap (append room): rows_in N -> rows_out N+8
+    y2 = torch.zeros(B * (N + 8), D, device=dev, dtype=torch.bfloat16)
+    ops.norm_modulate(x, y2, B * N, D, kind=0, eps=1e-6, rows_in=N, rows_out=N + 8)
+    ref2 = torch.nn.functional.layer_norm(x, (D,), eps=1e-6).reshape(B, N, D)
+    assert rel_l2(y2.reshape(B, N + 8, D)[:, :N].float(), ref2) < 4e-3
+    assert float(y2.reshape(B, N + 8, D)[:, N:].abs().max()) == 0
+
+
+def test_rmsnorm_heads(ops):
+    dev = 'cuda'
+    x = torch.randn(1000, 64, device=dev).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(64, device=dev))
+    ref = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    y = x.clone()
+    ops.rmsnorm_heads(y, w, 1000, 64)
+    assert rel_l2(y.float(), ref) < 4e-3
+
+
+def test_timestep_patch_final(ops):
+    from oracle import dit as odit
+    dev = 'cuda'
+    t = torch.tensor([0.0, 1.0, 37.0, 999.0, 0.25])
+    out = torch.empty(5, 256, device=dev, dtype=torch.bfloat16)
+    ops.timestep_embedding(t.to(dev), out, 5, 256)
+    assert rel_l2(out.float(), odit.timestep_embedding(t)) < 4e-3
+    # patch embed vs oracle
+    D, C, S, p = 128, 4, 32, 2
+    g = torch.Generator().manual_seed(0)
+    sd = {'x_embedder.proj.weight': torch.randn(D, C, p, p, generator=g), 'x_embedder.proj.bias': torch.randn(D, generator=g)}
+    pos = odit.trilatent_pos_embed(D)
+    x = torch.randn(2, 12, S, S, generator=g)
+    ref = odit.patchify_embed(sd, torch.cat([x, x]) * torch.tensor([1., 1., .5, .5]).view(4, 1, 1, 1)) + pos
+    tok = torch.empty(4 * 768, D, device=dev)
+    ops.patch_embed(x.to(dev), torch.tensor([1., 1., .5, .5], device=dev), sd['x_embedder.proj.weight'].reshape(D, -1).to(dev),
+                    sd['x_embedder.proj.bias'].to(dev), pos[0].to(dev), tok, 2, 4, C, S, p, D)
+    assert rel_l2(tok.reshape(4, 768, D), ref) < 1e-5
+    # final layer vs oracle math
+    h = torch.randn(2, 768, D, generator=g)
+    mod = torch.randn(2, 2 * D, generator=g)
+    wf, bf_ = torch.randn(16, D, generator=g) * 0.1, torch.randn(16, generator=g)
+    yr = torch.nn.functional.layer_norm(h, (D,), eps=1e-6) * (1 + mod[:, None, D:]) + mod[:, None, :D]
+    yr = odit.unpatchify_trilatent(torch.nn.functional.linear(yr, wf, bf_), 2, 2, 4)
+    o = torch.empty(2, 12, 32, 32, device=dev)
+    md = mod.to(dev)
+    ops.final_layer(h.to(dev).reshape(-1, D), md[:, :D], md[:, D:], 2 * D, None, None, wf.to(dev), bf_.to(dev), o, 2, 4, 32, 2, D)
+    assert rel_l2(o, yr) < 1e-5
+
+
+def test_sampler_steps(ops):
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 12, 32, 32, generator=g)
+    eps2 = torch.randn(4, 12, 32, 32, generator=g)
+    sig, nxt, s = 3.7, 3.1, 6.5
+    den = x - sig * eps2
+    du, dc = den[:2] if False else (x - sig * eps2[:2]), (x - sig * eps2[2:])
+    d = du + s * (dc - du)
+    ref = x + (x - d) / sig * (nxt - sig)
+    xd = x.to(dev).clone()
+    ops.edm_euler_step(xd, eps2.to(dev), sig, nxt, s)
+    assert rel_l2(xd, ref) < 1e-5
+    v2 = torch.randn(4, 12, 32, 32, generator=g)
+    x2 = torch.cat([x, x]).to(dev)
+    ops.flow_euler_step(x2, v2.to(dev), 0.02, 4.0)
+    v = v2[2:] + 4.0 * (v2[:2] - v2[2:])
+    assert rel_l2(x2[:2], x + 0.02 * v) < 1e-6 and torch.equal(x2[:2], x2[2:])

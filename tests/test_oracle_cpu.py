@@ -1,0 +1,135 @@
+"""CPU suite: the oracle against the committed golden vectors (produced by the REFERENCE in the build
+container, tests/golden/make_golden.py), host logic, and that the C-ABI library loads and exports every
+symbol of include/ln3d.h.  No compute calls into the HIP library here (no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, manifest, rel_l2
+from ln3diff_amd.synth import synth_input, synth_state_dict, orbit_cameras
+from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec
+
+
+def _sd_from_manifest(g, key='manifest'):
+    shapes = manifest(g, key)
+    computed = {}
+    for k, s in shapes.items():
+        if k == 'pos_embed':
+            computed[k] = odit.trilatent_pos_embed(s[-1])
+        elif k.endswith('vit_decoder.pos_embed'):
+            computed[k] = odec.decoder_pos_embed(s[-1])
+    return synth_state_dict(shapes, 0, computed)
+
+
+def test_abi_library_loads_and_exports_header_symbols(hip_lib):
+    from ln3diff_amd import _lib
+    assert _lib.check_symbols()
+    hdr = open(os.path.join(ROOT, 'include', 'ln3d.h')).read()
+    declared = set(re.findall(r'\b(ln3d_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'ln3d_gemm_args', 'ln3d_attn_args', 'ln3d_norm_args', 'ln3d_render_args'}
+    for s in declared:
+        assert hasattr(hip_lib, s), s
+    assert declared <= set(_lib.SYMBOLS) | {'ln3d_strerror'}
+
+
+def test_product_fails_loudly_without_gpu():
+    from ln3diff_amd.dit.dit_trilatent import DiT_TriLatent
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    m = DiT_TriLatent(hidden_size=128, depth=1, num_heads=2, num_classes=0, learn_sigma=False, context_dim=768,
+                      roll_out=True, vit_blk=TextCondDiTBlock)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 12, 32, 32), torch.zeros(1), torch.zeros(1, 77, 768))
+
+
+def test_oracle_t23d_tiny_matches_reference_golden():
+    g = golden('t23d_tiny')
+    sd = _sd_from_manifest(g)
+    x = synth_input('x', (2, 12, 32, 32), 0)
+    ctx = synth_input('ctx', (2, 77, 768), 0)
+    y = odit.t23d_forward(sd, x, torch.from_numpy(g['t']), ctx, 2)
+    assert rel_l2(y, g['y']) < 1e-5
+
+
+def test_oracle_i23d_tiny_matches_reference_golden():
+    g = golden('i23d_tiny')
+    sd = _sd_from_manifest(g)
+    x = synth_input('x', (4, 12, 32, 32), 0)
+    ctx = {'crossattn': synth_input('ca', (4, 256, 2048), 0), 'vector': synth_input('v', (4, 768), 0)}
+    y = odit.i23d_forward_with_cfg(sd, x, torch.from_numpy(g['t']), ctx, 4.0, 2)
+    assert rel_l2(y, g['y']) < 1e-5
+
+
+def test_oracle_edm_euler_matches_reference_golden():
+    g = golden('edm_tiny_10')
+    sd = _sd_from_manifest(golden('t23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (2, 77, 768), 41), 'vector': synth_input('v', (2, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    assert torch.equal(osamp.legacy_ddpm_sigmas(10), torch.from_numpy(g['sigmas']))
+    tr = []
+    y = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2), z, cond, uc, 10, 6.5, tr)
+    assert rel_l2(tr[0], g['first']) < 1e-5 and rel_l2(y, g['final']) < 1e-4
+    s250 = osamp.legacy_ddpm_sigmas(250)
+    assert abs(float(s250[0]) - 14.6146) < 1e-3 and abs(float(s250[249]) - 0.0586) < 1e-3 and float(s250[250]) == 0
+
+
+def test_oracle_flow_heun_matches_reference_golden():
+    g = golden('flow_tiny_heun10')
+    sd = _sd_from_manifest(golden('i23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 42)
+    cond = {'crossattn': synth_input('ca', (2, 256, 2048), 42), 'vector': synth_input('v', (2, 768), 42)}
+    ctx = {k: torch.cat([v, torch.zeros_like(v)], 0) for k, v in cond.items()}
+    y = osamp.flow_ode_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], 4.0, 2),
+                              torch.cat([z, z]), 10, 'heun', context=ctx).chunk(2)[0]
+    assert rel_l2(y, g['final']) < 1e-4
+
+
+def test_schedule_tables():
+    assert osamp.space_timesteps(1000, 'ddim250') == set(range(0, 1000, 4))
+    s50 = sorted(osamp.space_timesteps(1000, '50'))
+    assert s50[0] == 0 and s50[-1] == 999 and len(s50) == 50
+    tb = osamp.SpacedTables('50')
+    assert tb.timestep_map == s50 and abs(np.prod(1 - tb.betas) - np.cumprod(1 - osamp.linear_betas())[-1]) < 1e-12
+
+
+def _dec_sd(bias):
+    shapes = {'net.0.weight': (64, 32), 'net.0.bias': (64,), 'net.2.weight': (4, 64), 'net.2.bias': (4,)}
+    sd = synth_state_dict(shapes, 0)
+    sd['net.2.bias'] = sd['net.2.bias'].clone()
+    sd['net.2.bias'][0] += bias
+    return sd
+
+
+@pytest.mark.parametrize('tag,res,V', [('dense_r16', 16, 2), ('sparse_r16', 16, 1)])
+def test_oracle_render_matches_reference_golden(tag, res, V):
+    from ln3diff_amd.nsr.triplane import draw_render_noise
+    g = golden('render_' + tag)
+    planes = synth_input('planes', (V, 96, 128, 128), 3, float(g['plane_scale']))
+    gen = torch.Generator().manual_seed(int(g['jitter_seed']))
+    j, u = draw_render_noise(V, res * res, 64, generator=gen)
+    r = orender.triplane_render(planes, _dec_sd(float(g['sigma_bias'])), torch.from_numpy(g['cams']), res,
+                                j.unsqueeze(-1), u)
+    for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
+        assert rel_l2(r[k], g[k]) < 1e-4, k
+    if tag.startswith('sparse'):     # the batch-global depth clamp quirk: every pixel == global min depth
+        assert float(r['image_depth'].max() - r['image_depth'].min()) == 0.0
+    assert np.allclose(orbit_cameras(8)[[1, 6][:V]].numpy(), g['cams'])
+
+
+def test_oracle_grid_matches_reference_golden():
+    g = golden('grid16')
+    planes = synth_input('planes', (1, 96, 128, 128), 3, 4.0)
+    r = orender.decode_grid(planes, _dec_sd(4.0), 16)
+    assert rel_l2(r['sigma'][0, ..., 0], g['sigma']) < 1e-5 and rel_l2(r['rgb'][0], g['rgb']) < 1e-5
+
+
+def test_oracle_decode_tiny_matches_reference_golden():
+    g = golden('decode_tiny')
+    sd = _sd_from_manifest(g)
+    latent = synth_input('latent', (2, 12, 32, 32), 5)
+    planes = odec.vae_decode(sd, latent, 2)
+    assert rel_l2(planes[:, :, ::8, ::8], g['planes_sub']) < 1e-4
+    assert abs(float(planes.std()) - float(g['planes_std'])) < 1e-4
