@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py - 3D samples/sec of the text->3D sampling hot path on MI355X (driver contract in the task brief).
+
+One "step" = one pass of the whole hot path over one batch of B samples per GPU:
+  noise z[B,12,32,32] -> EulerEDM x 250 steps with CFG 6.5 (500 DiT-L/2 forwards per sample; LegacyDDPM sigmas,
+  the released T23D sampler) -> latent*0.96806 -> VAE decode (DiT2-L/2 + conv decoder) -> V views @ res^2 through
+  the fused tri-plane ray-marcher (64+64 samples/ray).  Weights: random-init of the named architectures; inputs:
+  synthetic noise / conditioning / orbit cameras, resident in HBM before the timed region.
+N GPUs: one process per GPU, weak scaling (B samples per rank), RCCL broadcast of rank 0's weights at start-up,
+all_gather of the final latents inside the timed region; no collective inside the denoise loop.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_models(dev, arch, dec_arch, seed=0, fill=True):
+    from ln3diff_amd.dit.dit_trilatent import DiT_models
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    from ln3diff_amd.dit.dit_decoder import DiT2_models
+    from ln3diff_amd.nsr.triplane import Triplane
+    from ln3diff_amd.vit.vit_triplane import (
+        RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder as Dec)
+    from ln3diff_amd.synth import fill_module_random_
+    dit = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768,
+                           roll_out=True, vit_blk=TextCondDiTBlock)
+    vit = DiT2_models[dec_arch](input_size=16, num_classes=0, learn_sigma=False, in_channels=dit.embed_dim,
+                                mixed_prediction=False, context_dim=None, roll_out=True, plane_n=3)
+    dec = Dec(vit_decoder=vit, triplane_decoder=Triplane(img_resolution=128), cls_token=False, vae_p=2,
+              ldm_z_channels=4, ldm_embed_dim=4)
+    dit, dec = dit.to(dev), dec.to(dev)
+    if fill:
+        fill_module_random_(dit, seed, dev)
+        fill_module_random_(dec, seed + 1, dev)
+        # keep the synthetic volume non-empty so compositing is exercised
+        dec.triplane_decoder.decoder.net[2].bias.data[0] += 4.0
+    return dit, dec
+
+
+def roofline_probe(dev, n_net, D, iters=20):
+    """Live HIP-event timing of the dominant kernel of the step: the MLP fc1 GEMM (gemm_bf16_kernel<GELU_ERF>,
+    M = n_net*768 tokens, N = 4D, K = D) at the workload's exact shape, on the stream it is launched on."""
+    from ln3diff_amd import ops
+    M, N, K = n_net * 768, 4 * D, D
+    x = (torch.randn(M, K, device=dev) * 1.0).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) * 0.02
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(x, w, b, ops.EPI_GELU_ERF, y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(x, w, b, ops.EPI_GELU_ERF, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * N * K
+    peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_bf16_kernel<GELU_ERF> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(ms * 1e3, 2)}
+
+
+def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20):
+    from ln3diff_amd import ops
+    q = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
+    k = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
+    vt = torch.randn(n_net, H, Dh, N, device=dev).to(torch.bfloat16)
+    o = torch.empty(n_net, N, H * Dh, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.attention(q, k, vt, o, n_net, H, N, N, N, N, Dh)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.attention(q, k, vt, o, n_net, H, N, N, N, N, Dh)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 4.0 * N * N * H * Dh * n_net          # 4*Nq*Nkv*(H*Dh) per sample-layer
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "attn_kernel<64> (DiT-L/2 self-attention)", "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2)}
+
+
+def render_probe(dev, dec, res=256, V=4, iters=5):
+    from ln3diff_amd.synth import orbit_cameras
+    tp = dec.triplane_decoder
+    pcl = torch.randn(1, 3, 128, 128, 32, device=dev) * 4.0
+    cams = orbit_cameras(V).to(dev)
+    idx = torch.zeros(V, dtype=torch.int32, device=dev)
+    j = torch.rand(V, res * res, 64, device=dev)
+    u = torch.rand(V * res * res, 64, device=dev)
+    tp(c=cams, planes_channel_last=pcl, plane_index=idx, neural_rendering_resolution=res, jitter=j, u_fine=u)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        tp(c=cams, planes_channel_last=pcl, plane_index=idx, neural_rendering_resolution=res, jitter=j, u_fine=u)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    pts = V * res * res * 128
+    gbytes = pts * 1536.0 / 1e9                    # 3 planes x 4 taps x 32 ch x 4 B per sample point
+    ach = gbytes / (ms * 1e-3)
+    return {"kernel": "render_kernel (fused tri-plane ray-march, %dx%d^2 views)" % (V, res), "bound": "hbm",
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+            "definition": "algorithmic gather bytes (1536 B/sample point); texels are L2/MALL-resident, see DESIGN.md",
+            "ms_per_view": round(ms / V, 3)}
+
+
+def cpu_baseline(arch, steps_total, views, res, B):
+    """CPU restatement (oracle/, validated against the reference's own Python in the build container) timed on
+    this box's host cores on a bounded sample of the same workload, extrapolated linearly (per-step and per-view
+    costs are constant): 2 timed EDM steps at B=1 (network batch 2, CFG), 1 VAE decode at B=1, 1 view."""
+    from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec
+    from ln3diff_amd.synth import orbit_cameras
+    from ln3diff_amd.dit.dit_trilatent import DiT_models
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    hidden, depth, heads = odit.DIT_CONFIGS[arch]
+    t_all = time.time()
+    m = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                         vit_blk=TextCondDiTBlock)
+    sd = {k: v for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    for k, v in sd.items():
+        if 'pos_embed' not in k and ('adaLN' in k or 'final_layer' in k):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.02)
+    z = torch.randn(1, 12, 32, 32, generator=g)
+    cond = {'crossattn': torch.randn(1, 77, 768, generator=g)}
+    uc = {'crossattn': torch.zeros(1, 77, 768)}
+    table = osamp.discrete_denoiser_table()
+    sig = osamp.legacy_ddpm_sigmas(250)
+    net = lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads)
+    with torch.no_grad():
+        osamp.edm_denoise_cfg(net, z, sig[:1], cond, uc, 6.5, table)       # warm-up
+        t0 = time.time()
+        for i in range(2):
+            osamp.edm_denoise_cfg(net, z, sig[i:i + 1], cond, uc, 6.5, table)
+        t_step = (time.time() - t0) / 2
+        # render: 1 view at res^2 (planes random; decoder default)
+        dec_sd = {'net.0.weight': torch.randn(64, 32, generator=g), 'net.0.bias': torch.zeros(64),
+                  'net.2.weight': torch.randn(4, 64, generator=g), 'net.2.bias': torch.tensor([4., 0, 0, 0])}
+        planes = torch.randn(1, 96, 128, 128, generator=g) * 4
+        rr = min(res, 64)
+        jit = torch.rand(1, rr * rr, 64, 1, generator=g)
+        uf = torch.rand(rr * rr, 64, generator=g)
+        t0 = time.time()
+        orender.triplane_render(planes, dec_sd, orbit_cameras(1), rr, jit, uf)
+        t_view = (time.time() - t0) * (res / rr) ** 2
+    # VAE decode: DiT2-L/2 (734 GFLOP) ~ 1.2x one CFG DiT step (2 x 613 GFLOP) -> scaled from the measured step
+    t_dec = t_step * (734.0 + 20.0) / (2 * 613.0)
+    per_sample = steps_total * t_step + t_dec + views * t_view
+    return {"value": round(1.0 / per_sample, 6), "unit": "3D samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads): 2 timed EulerEDM+CFG steps at B=1 "
+                      "(%.2f s/step) x %d, VAE decode scaled by FLOPs (%.2f s), 1 view at %d^2 scaled to %d^2 "
+                      "(%.2f s/view) x %d views; wall %.0f s" % (cores, t_step, steps_total, t_dec, rr, res, t_view,
+                                                                   views, time.time() - t_all)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE config 2: batch 8)")
+    ap.add_argument("--sample-steps", type=int, default=250)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--arch", default="DiT-L/2")
+    ap.add_argument("--dec-arch", default="DiT2-L/2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probes", action="store_true")
+    args = ap.parse_args()
+
+    from ln3diff_amd import parallel
+    from ln3diff_amd.pipeline import T23DPipeline
+    from ln3diff_amd.synth import orbit_cameras
+    rank, local_rank, world = parallel.setup_dist()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    # rank 0 creates the weights, every rank receives them by ONE flat RCCL broadcast per dtype
+    dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0))
+    if world > 1:
+        parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] +
+                                [b for b in dec.buffers()], src=0)
+    pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
+
+    B, Bt = args.batch, args.batch * world
+    g = torch.Generator(device=dev).manual_seed(41)            # global seed, full batch, then sliced per rank
+    z_all = torch.randn(Bt, 12, 32, 32, device=dev, generator=g)
+    c_all = torch.randn(Bt, 77, 768, device=dev, generator=g)
+    lo, hi = parallel.shard_range(Bt, rank, world)
+    cond = {'crossattn': c_all[lo:hi].contiguous()}
+    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+    cams = orbit_cameras(args.views).to(dev)
+
+    def one_step():
+        latent, img = pipe(z_all[lo:hi].clone(), cond, uc, cams, args.res)
+        lat_all = parallel.all_gather_cat(latent)
+        return lat_all, img
+
+    for _ in range(args.warmup):
+        out = one_step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt)
+    ok = bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]['image_raw']).all())
+
+    if rank == 0:
+        rec = {
+            "metric": "3D samples/sec (250-step DiT-L/2 + triplane decode + render)", "value": round(Bt * args.steps / dt, 5),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %s text-cond T23D, EulerEDM/LegacyDDPM-sigma %d steps, CFG 6.5 "
+                                   "(network batch 2B), batch %d per GPU, VAE decode %s + conv decoder, %d views @ %d^2 "
+                                   "(64+64 samples/ray)" % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res),
+                       "global_batch": Bt, "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
+            "finite": ok,
+        }
+        if not args.no_probes:
+            D = dit.embed_dim
+            rec["roofline"] = roofline_probe(dev, 2 * B, D)
+            rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 768, D // dit.num_heads)
+            rec["roofline_raymarch"] = render_probe(dev, dec)
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B)
+        print(json.dumps(rec), flush=True)
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

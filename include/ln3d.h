@@ -117,6 +117,14 @@ int ln3d_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 int ln3d_patch_embed(const float* x, const float* in_scale, const float* w, const float* bias,
                      const float* pos, float* tokens, int Bx, int Bn, int C, int S, int p, int D, void* stream);
 
+/* PatchEmbedTriplane of the VAE decoder (vit/vit_triplane.py:58-110): latent f32 [B, 3*Cg, S, S] -> per-token
+ * conditioning c [B, 3*L, D]; emitted as bf16 silu(c) (the only form DiTBlock2's adaLN consumes) and
+ * optionally raw f32.  w f32 [3*D, Cg, p, p] (groups = 3), bias [3*D].                                  */
+int ln3d_patch_embed_triplane(const float* latent, const float* w, const float* bias, void* out_silu_bf16,
+                              float* out_raw, int B, int Cg, int S, int p, int D, void* stream);
+/* y[r*per + i] = x[i] for r < reps (DiT2 queries start from pos_embed, dit/dit_decoder.py:104-105) */
+int ln3d_tile_rows(const float* x, float* y, int64_t per, int reps, void* stream);
+
 /* FinalLayer / T2IFinalLayer + unpatchify (dit/dit_models_xformers.py:655-678, :61-84, :821-835,
  * dit/dit_trilatent.py:128-140): LN(eps 1e-6) -> *(1+scale)+shift -> Linear(D -> p*p*C) -> [Bn, C*3, S, S] f32.
  *   shift/scale f32 per sample at [b*mod_ld + d]; optional tables added.                              */

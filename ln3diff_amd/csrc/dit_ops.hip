@@ -154,6 +154,54 @@ extern "C" int ln3d_patch_embed(const float* x, const float* in_scale, const flo
   return ln3d_check_launch();
 }
 
+// ------------------------------------------------------------------ PatchEmbedTriplane (VAE decoder tokeniser)
+// grouped conv (groups=3) + literal channel regroup of vit/vit_triplane.py:82-106, emitted as silu(c) in bf16
+// because the decoder only ever consumes c through adaLN_modulation = Linear(SiLU(c)) (dit/dit_decoder.py:27-28):
+//   oc = d*3 + j, group g = oc / D ;  c[b, j*L + l, d] = bias[oc] + sum_{cc,ky,kx} w[oc,cc,ky,kx] * latent[b, g*Cg + cc, p*ph+ky, p*pw+kx]
+__global__ __launch_bounds__(256) void patch_embed_triplane_kernel(const float* latent, const float* w, const float* bias,
+                                                                   bf16_t* out_silu, float* out_raw, int Cg, int S, int p, int D) {
+  const int G = S / p, L = G * G;
+  const int tok = blockIdx.x;            // b * 3L + j*L + l
+  const int b = tok / (3 * L), r = tok % (3 * L), j = r / L, l = r % L, ph = l / G, pw = l % G;
+  const int KK = Cg * p * p;             // per-group patch size (16)
+  __shared__ float patch[3 * 64];
+  if (threadIdx.x < 3 * KK) {
+    const int g = threadIdx.x / KK, k = threadIdx.x % KK;
+    const int cc = k / (p * p), ij = k % (p * p), ky = ij / p, kx = ij % p;
+    patch[threadIdx.x] = latent[(((int64_t)b * 3 * Cg + g * Cg + cc) * S + p * ph + ky) * S + p * pw + kx];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const int oc = d * 3 + j, g = oc / D;
+    float acc = bias[oc];
+    const float* wr = w + (int64_t)oc * KK;
+    for (int k = 0; k < KK; ++k) acc += wr[k] * patch[g * KK + k];
+    if (out_raw) out_raw[(int64_t)tok * D + d] = acc;
+    out_silu[(int64_t)tok * D + d] = f2bf(silu(acc));
+  }
+}
+extern "C" int ln3d_patch_embed_triplane(const float* latent, const float* w, const float* bias, void* out_silu_bf16,
+                                         float* out_raw, int B, int Cg, int S, int p, int D, void* stream) {
+  if (!latent || !w || !bias || !out_silu_bf16 || Cg * p * p > 64 || S % p) return LN3D_ERR_BAD_ARG;
+  const int L = (S / p) * (S / p);
+  hipLaunchKernelGGL(patch_embed_triplane_kernel, dim3(B * 3 * L), dim3(256), 0, (hipStream_t)stream, latent, w, bias,
+                     (bf16_t*)out_silu_bf16, out_raw, Cg, S, p, D);
+  return ln3d_check_launch();
+}
+
+// broadcast rows: y[b, :, :] = x[:, :] (DiT2 starts from the positional embedding, dit/dit_decoder.py:104-105)
+__global__ void tile_rows_kernel(const float4* x, float4* y, int64_t per4, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total4) y[i] = x[i % per4];
+}
+extern "C" int ln3d_tile_rows(const float* x, float* y, int64_t per, int reps, void* stream) {
+  if (!x || !y || per % 4) return LN3D_ERR_BAD_ARG;
+  const int64_t total4 = per / 4 * reps;
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (float4*)y, per / 4, total4);
+  return ln3d_check_launch();
+}
+
 // ------------------------------------------------------------------ final layer (+unpatchify)
 struct FinalP {
   const float* tokens; const float* shift; const float* scale; int64_t mod_ld;

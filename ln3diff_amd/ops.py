@@ -140,3 +140,12 @@ def groupnorm_swish(x, w, b, y, stats, N, HW, Cc, groups=32, eps=1e-6, swish=Tru
 
 def im2col3x3(x, col, N, H, W, Cc, upsample, Kpad):
     L.check(L.lib().ln3d_im2col3x3(_p(x), _p(col), N, H, W, Cc, upsample, Kpad, _stream()), "im2col3x3")
+
+
+def patch_embed_triplane(latent, w, bias, out_silu, out_raw, B, Cg, S, p, D):
+    L.check(L.lib().ln3d_patch_embed_triplane(_p(latent), _p(w), _p(bias), _p(out_silu), _p(out_raw), B, Cg, S, p, D, _stream()),
+            "patch_embed_triplane")
+
+
+def tile_rows(x, y, per, reps):
+    L.check(L.lib().ln3d_tile_rows(_p(x), _p(y), C.c_int64(per), reps, _stream()), "tile_rows")

@@ -14,30 +14,48 @@ import zlib
 import torch
 
 
-def synth_tensor(name, shape, seed=0):
-    g = torch.Generator(device='cpu')
-    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+def _scale_rule(name, shape):
+    """(offset, scale) such that tensor = offset + scale * N(0,1)."""
     shape = tuple(shape)
-    r = torch.randn(shape, generator=g, dtype=torch.float32)
     leaf = name.rsplit('.', 1)[-1]
     if 'pos_embed' in name:
         raise ValueError('pos_embed is computed, not synthesised')
     if name.endswith('scale_shift_table'):
-        return r / shape[-1] ** 0.5
+        return 0.0, 1.0 / shape[-1] ** 0.5
     if leaf == 'weight' and len(shape) == 1:                 # norm scales
-        return 1.0 + 0.05 * r
+        return 1.0, 0.05
     if leaf == 'bias' or len(shape) == 1:
-        return 0.02 * r
+        return 0.0, 0.02
     if 'triplane_decoder' in name or name.startswith('net.'):  # OSGDecoder FullyConnectedLayer: N(0,1)
-        return r
-    if 'adaLN_modulation' in name:
-        return 0.02 * r
-    if 'final_layer.linear' in name:
-        return 0.02 * r
+        return 0.0, 1.0
+    if 'adaLN_modulation' in name or 'final_layer.linear' in name:
+        return 0.0, 0.02
     fan_in = 1
     for s in shape[1:]:
         fan_in *= s
-    return r * (0.7 / fan_in ** 0.5)
+    return 0.0, 0.7 / fan_in ** 0.5
+
+
+def synth_tensor(name, shape, seed=0):
+    g = torch.Generator(device='cpu')
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    off, sc = _scale_rule(name, shape)
+    r = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    if name.endswith('scale_shift_table'):
+        return r / tuple(shape)[-1] ** 0.5          # bit-exact with the recipe the goldens were made with
+    return r * sc + off if off else r * sc
+
+
+def fill_module_random_(module, seed=0, device=None):
+    """Fast variant for bench.py: same scale rules, device RNG, in place (not golden-reproducible)."""
+    g = torch.Generator(device=device or 'cpu')
+    g.manual_seed(seed)
+    for k, v in module.state_dict().items():
+        if 'pos_embed' in k or not v.dtype.is_floating_point:
+            continue
+        off, sc = _scale_rule(k, v.shape)
+        v.copy_(torch.randn(v.shape, generator=g, device=g.device, dtype=torch.float32).mul_(sc).add_(off))
+    return module
 
 
 def synth_state_dict(shapes, seed=0, computed=None):

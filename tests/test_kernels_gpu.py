@@ -203,8 +203,7 @@ def test_sampler_steps(ops):
     x = torch.randn(2, 12, 32, 32, generator=g)
     eps2 = torch.randn(4, 12, 32, 32, generator=g)
     sig, nxt, s = 3.7, 3.1, 6.5
-    den = x - sig * eps2
-    du, dc = den[:2] if False else (x - sig * eps2[:2]), (x - sig * eps2[2:])
+    du, dc = (x - sig * eps2[:2]), (x - sig * eps2[2:])
     d = du + s * (dc - du)
     ref = x + (x - d) / sig * (nxt - sig)
     xd = x.to(dev).clone()
