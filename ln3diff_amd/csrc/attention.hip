@@ -140,14 +140,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(st[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
         st[kt][r] = pv;
         psum += pv;
       }

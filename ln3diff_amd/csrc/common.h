@@ -42,7 +42,20 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, one v_exp + one v_rcp): the epilogue rounds to bf16 (2^-9)
+// right after, and the libm erff costs ~3x the GEMM's own epilogue budget at K = 1024.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));

@@ -15,6 +15,7 @@
 //    16 MFMAs/wave), one barrier per K-tile.
 //  * Epilogues fused: bias, GELU(erf/tanh), SiLU, gate*out+residual (adaLN-zero gating into the fp32
 //    residual stream, optional bf16 copy), head split with V^T emission for the attention kernel.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ln3d.h"
 
@@ -194,6 +195,193 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   }
 }
 
+// =================================================================================================
+// Large-tile variant: 128(features) x 384(tokens) x 32(K) stages, 8 waves (2 x 4), wave tile 64f x 96t
+// (2 x 3 MFMA 32x32x16 tiles, 96 accumulator registers), 4-deep LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: HBM/L2 -> LDS without touching VGPRs), counted vmcnt so that the loads of the
+// next two stages stay in flight ACROSS the per-stage barrier (raw s_barrier; __syncthreads would drain them).
+//  * LDS rows are 64 B (32 bf16) and XOR-swizzled at 16-B granularity: chunk c of row r lives at position
+//    c ^ ((r>>2)&3).  The DMA writes lane-linear (base + 16*lane), so the swizzle is applied to the per-lane
+//    SOURCE address and again on the ds_read_b128 side; a b128 lane-group (16 distinct rows) then covers all 16
+//    16-B slots of the 256-B bank row: conflict-free without padding.
+//  * Tile shape chosen so the DiT GEMMs quantise exactly onto 256 CUs at one 8-wave workgroup per CU:
+//    tokens 16*768 = 32 x 384; N = 1024 / 3072 / 4096 -> 256 / 768 / 1024 tiles = 1 / 3 / 4 full rounds.
+//  * Workgroup -> tile map is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a contiguous range
+//    of tile ids, feature-tile fastest, so the workgroups sharing one token panel hit the same L2.
+#define L_BF 128
+#define L_BT 384
+#define L_BK 32
+#define L_STAGES 4
+#define L_WB (L_BF * 64)                 // 8192
+#define L_XB (L_BT * 64)                 // 24576
+#define L_STAGEB (L_WB + L_XB)           // 32768
+#define L_LDS (L_STAGES * L_STAGEB)      // 131072
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// ABL (bench-only ablations, tools/kbench.py): 0 = product kernel, 1 = no LDS-DMA (stale LDS), 2 = no MFMA, 3 = no ds_read
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_large_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wid >> 2, wt = wid & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware bijective tile map
+  const int nft = (p.N + L_BF - 1) / L_BF, ntt = (p.M + L_BT - 1) / L_BT;
+  const int ntiles = nft * ntt;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ft = tile % nft, tt = tile / nft;
+  const int f0 = ft * L_BF, t0 = tt * L_BT;
+
+  // LDS-DMA source pointers: instruction j of a tile covers rows [16j, 16j+16); lane -> (row 16j + lane/4,
+  // stored position lane%4 holding global chunk (lane%4) ^ ((lane>>4)&3))
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  int rw = f0 + 16 * wid + lrow; rw = rw < p.N ? rw : p.N - 1;
+  const bf16_t* wsrc = p.W + (int64_t)rw * p.ldw + lchunk * 8;
+  const bf16_t* xsrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int rx = t0 + 16 * (wid + 8 * i) + lrow; rx = rx < p.M ? rx : p.M - 1;
+    xsrc[i] = p.X + (int64_t)rx * p.ldx + lchunk * 8;
+  }
+  const int wdst = wid * 1024;
+  const int xdst0 = L_WB + wid * 1024, xdst1 = L_WB + (wid + 8) * 1024, xdst2 = L_WB + (wid + 16) * 1024;
+
+#define L_ISSUE(s)                                                                                        \
+  {                                                                                                       \
+    const int koff_ = (s) * L_BK;                                                                         \
+    char* sb_ = smem + ((s) & (L_STAGES - 1)) * L_STAGEB;                                                 \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + koff_), (lds_void_t*)(sb_ + wdst), 16, 0, 0);    \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[0] + koff_), (lds_void_t*)(sb_ + xdst0), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[1] + koff_), (lds_void_t*)(sb_ + xdst1), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[2] + koff_), (lds_void_t*)(sb_ + xdst2), 16, 0, 0); \
+  }
+
+  // fragment read offsets (ks = 0; ks = 1 is the same address ^ 32)
+  const int key = (l31 >> 2) & 3;
+  const int a_off = (wf * 64 + l31) * 64 + ((hi ^ key) << 4);
+  const int b_off = L_WB + (wt * 96 + l31) * 64 + ((hi ^ key) << 4);
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Software pipeline, one barrier per 32-deep stage, all 8 waves in step:
+  //   iteration s :  wait (counted) until THIS wave's DMAs of stage s+1 landed -> s_barrier (now every wave's have,
+  //                  and every wave has finished reading ring slot s) -> issue the DMAs of stage s+4 into slot s ->
+  //                  MFMAs on the register fragments of stage s, interleaved with the ds_reads of stage s+1 into
+  //                  the other fragment set.
+  // The fragments of a stage live in registers one iteration before they are multiplied, so a ring slot is free as
+  // soon as it has been read: 3 stages (96 KB per CU) of LDS-DMA stay in flight across the barriers, and the matrix
+  // pipe of a SIMD always has the 12 MFMAs of one of its two waves to run while the other issues DMA / LDS reads.
+  bf16x8 fa0[2][2], fb0[2][3], fa1[2][2], fb1[2][3];
+#define L_READ(s, FA, FB)                                                                              \
+  {                                                                                                    \
+    const char* sb_ = smem + ((s) & (L_STAGES - 1)) * L_STAGEB;                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
+          FA[ks][i] = *reinterpret_cast<const bf16x8*>(sb_ + ((a_off + i * 32 * 64) ^ (ks << 5)));     \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                    \
+          FB[ks][j] = *reinterpret_cast<const bf16x8*>(sb_ + ((b_off + j * 32 * 64) ^ (ks << 5)));     \
+    }                                                                                                  \
+  }
+#define L_MMA(FA, FB)                                                                                  \
+  {                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[ks][i], FB[ks][j], acc[i][j], 0, 0, 0); \
+  }
+  // one pipeline iteration: CUR = fragment set holding stage s, NXT = set receiving stage s+1
+#define L_ITER(s, CUR_A, CUR_B, NXT_A, NXT_B)                                                          \
+  {                                                                                                    \
+    if ((s) + 1 < ns) {                                                                                \
+      if ((s) + 3 < ns) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }                           \
+      else if ((s) + 2 < ns) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                      \
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                        \
+      __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): fragment reads of stage s done (compiler-visible) */ \
+      __builtin_amdgcn_s_barrier();                                                                    \
+      if constexpr (ABL != 1) { if ((s) + 4 < ns) L_ISSUE((s) + 4); }                                  \
+      if constexpr (ABL != 3) { L_READ((s) + 1, NXT_A, NXT_B); }                                       \
+    }                                                                                                  \
+    if constexpr (ABL != 2) { L_MMA(CUR_A, CUR_B); }                                                   \
+    else { asm volatile("" ::"v"(CUR_A[0][0]), "v"(CUR_B[1][2])); }                                    \
+  }
+
+  const int ns = p.K / L_BK;
+  L_ISSUE(0);
+  if (ns > 1) L_ISSUE(1);
+  if (ns > 2) L_ISSUE(2);
+  if (ns > 3) L_ISSUE(3);
+  if (ns > 3) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+  else if (ns > 2) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+  else if (ns > 1) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();                       // stage 0 of every wave has landed
+  L_READ(0, fa0, fb0);
+  // steady state (branch-free body so hipcc can interleave the ds_reads of stage s+1 under the MFMAs of stage s)
+#define L_STEADY(s, CUR_A, CUR_B, NXT_A, NXT_B)                                                        \
+  {                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    if constexpr (ABL != 1) { L_ISSUE((s) + 4); }                                                      \
+    if constexpr (ABL != 3) { L_READ((s) + 1, NXT_A, NXT_B); }                                         \
+    if constexpr (ABL != 2) { L_MMA(CUR_A, CUR_B); }                                                   \
+    else { asm volatile("" ::"v"(CUR_A[0][0]), "v"(CUR_B[1][2])); }                                    \
+  }
+  int s = 0;
+  for (; s + 5 < ns; s += 2) {
+    L_STEADY(s, fa0, fb0, fa1, fb1);
+    L_STEADY(s + 1, fa1, fb1, fa0, fb0);
+  }
+  for (; s < ns; s += 2) {                            // drain: <= 6 stages, counted waits shrink with the queue
+    L_ITER(s, fa0, fb0, fa1, fb1);
+    if (s + 1 < ns) L_ITER(s + 1, fa1, fb1, fa0, fb0);
+  }
+
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tok = t0 + wt * 96 + j * 32 + l31;
+    if (tok >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = f0 + wf * 64 + i * 32 + 8 * g + 4 * hi;
+        if (fb < p.N)
+          epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+    }
+  }
+}
+
+template <int EPI, int ABL = 0>
+static int launch_large(const GemmP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_large_kernel<EPI, ABL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);
+    attr_set = true;
+  }
+  const int nft = (p.N + L_BF - 1) / L_BF, ntt = (p.M + L_BT - 1) / L_BT;
+  hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, ABL>), dim3(nft * ntt), dim3(512), L_LDS, s, p);
+  return ln3d_check_launch();
+}
+
 template <int EPI>
 static int launch(const GemmP& p, hipStream_t s) {
   static bool attr_set = false;
@@ -220,6 +408,36 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.tokens = a->tokens; p.tok_pad = a->tok_pad; p.heads = a->heads; p.head_dim = a->head_dim;
   p.transpose_mask = a->transpose_mask;
   hipStream_t s = (hipStream_t)stream;
+  // tile selection: the 128x384 LDS-DMA kernel when the problem fills its tiles, the 128x128 kernel otherwise
+  // (small M such as the per-sample adaLN / timestep GEMMs, narrow N such as the conv decoder's 32/64 channels)
+  const char* force = getenv("LN3D_GEMM_TILE");
+  bool large = a->M >= 1536 && a->N >= 128;
+  if (force && force[0] == 's') large = false;
+  if (force && force[0] == 'l') large = true;
+  if (large) {
+    switch (a->epilogue) {
+      case LN3D_EPI_F32: return launch_large<LN3D_EPI_F32>(p, s);
+      case LN3D_EPI_BF16: {
+        const char* abl = getenv("LN3D_GEMM_ABL");
+        if (abl && abl[0] == '1') return launch_large<LN3D_EPI_BF16, 1>(p, s);
+        if (abl && abl[0] == '2') return launch_large<LN3D_EPI_BF16, 2>(p, s);
+        if (abl && abl[0] == '3') return launch_large<LN3D_EPI_BF16, 3>(p, s);
+        return launch_large<LN3D_EPI_BF16>(p, s);
+      }
+      case LN3D_EPI_GELU_ERF: return launch_large<LN3D_EPI_GELU_ERF>(p, s);
+      case LN3D_EPI_GELU_TANH: return launch_large<LN3D_EPI_GELU_TANH>(p, s);
+      case LN3D_EPI_SILU: return launch_large<LN3D_EPI_SILU>(p, s);
+      case LN3D_EPI_GATE_RES: return launch_large<LN3D_EPI_GATE_RES>(p, s);
+      case LN3D_EPI_F32_SILU:
+        if (!a->out1) return LN3D_ERR_BAD_ARG;
+        return launch_large<LN3D_EPI_F32_SILU>(p, s);
+      case LN3D_EPI_HEADS:
+        if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens)
+          return LN3D_ERR_BAD_ARG;
+        return launch_large<LN3D_EPI_HEADS>(p, s);
+      default: return LN3D_ERR_UNSUPPORTED;
+    }
+  }
   switch (a->epilogue) {
     case LN3D_EPI_F32: return launch<LN3D_EPI_F32>(p, s);
     case LN3D_EPI_BF16: return launch<LN3D_EPI_BF16>(p, s);

@@ -11,17 +11,29 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ops(hip_lib):
+@pytest.fixture(scope="module", params=["auto", "large", "small"])
+def ops(hip_lib, request):
+    """Every kernel test runs with the GEMM tile selection left to the library and forced to each tile config."""
+    import os
     from ln3diff_amd import ops as o
-    return o
+    old = os.environ.get("LN3D_GEMM_TILE")
+    if request.param == "auto":
+        os.environ.pop("LN3D_GEMM_TILE", None)
+    else:
+        os.environ["LN3D_GEMM_TILE"] = request.param[0]
+    yield o
+    if old is None:
+        os.environ.pop("LN3D_GEMM_TILE", None)
+    else:
+        os.environ["LN3D_GEMM_TILE"] = old
 
 
 def _bf(t):
     return t.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 192), (16, 1024, 256), (1536, 3072, 1024), (77, 512, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 192), (16, 1024, 256), (1536, 3072, 1024), (77, 512, 768),
+                                   (2000, 384, 128), (1636, 132, 320)])
 def test_gemm_plain_epilogues(ops, M, N, K):
     dev = 'cuda'
     g = torch.Generator().manual_seed(M + N + K)

@@ -28,7 +28,8 @@ def test_edm_euler_cfg_vs_reference_golden(hip_lib, steps):
     cond = {'crossattn': synth_input('c', (2, 77, 768), 41).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
     sampler = EulerEDMSampler(num_steps=steps, guider=VanillaCFG(6.5))
-    assert torch.equal(sampler.discretization(steps), torch.from_numpy(g['sigmas']))
+    # host libm/SIMD differences between machines move the fp32 table by an ulp: compare to 1e-6 relative
+    assert torch.allclose(sampler.discretization(steps), torch.from_numpy(g['sigmas']), rtol=1e-6, atol=0)
     den = DiscreteDenoiser()
     assert den.quantize(sampler.discretization(steps)[0])[1] == int(g['idx_first'][0])
     tr = []
