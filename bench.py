@@ -123,7 +123,7 @@ def cpu_baseline(arch, steps_total, views, res, B):
     from ln3diff_amd.synth import orbit_cameras
     from ln3diff_amd.dit.dit_trilatent import DiT_models
     from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)       # torch intra-op scaling collapses beyond ~32 threads at these GEMM sizes
     torch.set_num_threads(cores)
     hidden, depth, heads = odit.DIT_CONFIGS[arch]
     t_all = time.time()
@@ -141,16 +141,21 @@ def cpu_baseline(arch, steps_total, views, res, B):
     sig = osamp.legacy_ddpm_sigmas(250)
     net = lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads)
     with torch.no_grad():
-        osamp.edm_denoise_cfg(net, z, sig[:1], cond, uc, 6.5, table)       # warm-up
         t0 = time.time()
-        for i in range(2):
-            osamp.edm_denoise_cfg(net, z, sig[i:i + 1], cond, uc, 6.5, table)
-        t_step = (time.time() - t0) / 2
-        # render: 1 view at res^2 (planes random; decoder default)
+        osamp.edm_denoise_cfg(net, z, sig[:1], cond, uc, 6.5, table)       # first call (includes warm-up effects)
+        t_step = time.time() - t0
+        n_timed = 1
+        if t_step < 8.0:                                                    # bounded: only repeat when it is cheap
+            t0 = time.time()
+            for i in range(2):
+                osamp.edm_denoise_cfg(net, z, sig[i:i + 1], cond, uc, 6.5, table)
+            t_step = (time.time() - t0) / 2
+            n_timed = 2
+        # render: 1 view at a reduced resolution, scaled by ray count (cost is linear in rays)
         dec_sd = {'net.0.weight': torch.randn(64, 32, generator=g), 'net.0.bias': torch.zeros(64),
                   'net.2.weight': torch.randn(4, 64, generator=g), 'net.2.bias': torch.tensor([4., 0, 0, 0])}
         planes = torch.randn(1, 96, 128, 128, generator=g) * 4
-        rr = min(res, 64)
+        rr = min(res, 32)
         jit = torch.rand(1, rr * rr, 64, 1, generator=g)
         uf = torch.rand(rr * rr, 64, generator=g)
         t0 = time.time()
@@ -160,9 +165,9 @@ def cpu_baseline(arch, steps_total, views, res, B):
     t_dec = t_step * (734.0 + 20.0) / (2 * 613.0)
     per_sample = steps_total * t_step + t_dec + views * t_view
     return {"value": round(1.0 / per_sample, 6), "unit": "3D samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads): 2 timed EulerEDM+CFG steps at B=1 "
+            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads): %d timed EulerEDM+CFG step(s) at B=1 "
                       "(%.2f s/step) x %d, VAE decode scaled by FLOPs (%.2f s), 1 view at %d^2 scaled to %d^2 "
-                      "(%.2f s/view) x %d views; wall %.0f s" % (cores, t_step, steps_total, t_dec, rr, res, t_view,
+                      "(%.2f s/view) x %d views; wall %.0f s" % (cores, n_timed, t_step, steps_total, t_dec, rr, res, t_view,
                                                                    views, time.time() - t_all)}
 
 

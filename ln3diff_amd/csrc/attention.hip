@@ -15,6 +15,7 @@
 //    contraction-contiguous.  LDS rows are padded (K: 144 B for Dh=64, V^T: 136 B) which makes the
 //    ds_read_b128 / ds_read_b64 fragment reads bank-conflict free.  Tiles are double-buffered; the
 //    next block's global loads are issued before the MFMA work of the current block.
+#include <type_traits>
 #include "common.h"
 #include "../../include/ln3d.h"
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -3.0e38f, l_run = 0.f;
 
   const int nkb = (p.Nk + KVB - 1) / KVB;
 
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     if constexpr (VLD > 2) { LN3D_VSTORE(2, vr2); LN3D_VSTORE(3, vr3); } \
   }
 
-  auto process = [&](int kb, int buf) {
+  auto process = [&](int kb, int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const char* kt_ = kbuf + buf * KTILE;
     const char* vt_ = vbuf + buf * VTILE;
 
@@ -122,40 +124,45 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       }
     }
 
-    // ---- online softmax (lane-local over its 2x16 keys, one exchange with lane^32)
-    const int key_base = kb * KVB + 4 * hi;
-    const bool tail = (kb * KVB + KVB) > p.Nk;
-    float mx = -1e30f;
+    // ---- online softmax in the log2 domain (lane-local over its 2x16 keys, one exchange with lane^32):
+    //      p = exp2(s*c - m) as one FMA + one v_exp per element; the O rescale is skipped (wave-uniformly) when no
+    //      row maximum moved, which is exact (alpha == 1), not an approximation.
+    if constexpr (TAIL) {
+      const int key_base = kb * KVB + 4 * hi;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + kt * 32 + (r & 3) + 8 * (r >> 2);
+          st[kt][r] = key < p.Nk ? st[kt][r] : -3.0e38f;
+        }
+    }
+    float mx = -3.0e38f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = st[kt][r] * p.scale_log2;
-        if (tail) {
-          const int key = key_base + kt * 32 + (r & 3) + 8 * (r >> 2);
-          s = key < p.Nk ? s : -1e30f;
-        }
-        st[kt][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);     // scale > 0
+    if (!__all(m_new == m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      m_run = m_new;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], p.scale_log2, -m_new));
         st[kt][r] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    l_run += psum;
 
     // ---- P^T as B operand: step s uses tile s>>1, regs 8*(s&1)..+7  <->  keys 16s + 4hi + (j&3) + 8(j>>2)
     bf16x8 pb[4];
@@ -190,12 +197,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int buf = kb & 1;
     LN3D_GLOAD(kb + 1);
     __builtin_amdgcn_sched_barrier(0);
-    process(kb, buf);
+    process(kb, buf, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
     LN3D_LSTORE(buf ^ 1);
     __syncthreads();
   }
-  process(nkb - 1, (nkb - 1) & 1);
+  if ((p.Nk & (KVB - 1)) != 0) process(nkb - 1, (nkb - 1) & 1, std::true_type{});
+  else process(nkb - 1, (nkb - 1) & 1, std::false_type{});
 
   // ---- epilogue: O[b, q, h*DH + d] = O^T[d, q] / l
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);

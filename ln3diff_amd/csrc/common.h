@@ -22,8 +22,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two f32 -> packed bf16x2 (RNE) through the native conversion: hipcc selects v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -232,13 +232,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_large_kernel(GemmP p) {
   // XCD-aware bijective tile map
   const int nft = (p.N + L_BF - 1) / L_BF, ntt = (p.M + L_BT - 1) / L_BT;
   const int ntiles = nft * ntt;
-  int tile;
+  int ft, tt;
   {
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    if (r == 0 && (nft & 7) == 0 && q % nft == 0) {
+      // 2-D blocking inside the XCD's chunk: the 32 workgroups that run together on one XCD cover 8 feature tiles x
+      // 4 token panels (2 MB of W + 3 MB of X at K = 1024: L2-resident), and successive rounds keep the X panels.
+      const int rows = q / nft;                       // token panels owned by this XCD
+      const int g = slot / (rows * 8), rem = slot - g * rows * 8;
+      ft = g * 8 + (rem & 7);
+      tt = xcd * rows + (rem >> 3);
+    } else {
+      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+      ft = tile % nft; tt = tile / nft;
+    }
   }
-  const int ft = tile % nft, tt = tile / nft;
   const int f0 = ft * L_BF, t0 = tt * L_BT;
 
   // LDS-DMA source pointers: instruction j of a tile covers rows [16j, 16j+16); lane -> (row 16j + lane/4,
