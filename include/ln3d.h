@@ -145,6 +145,10 @@ int ln3d_ddpm_step(float* x, const float* eps, const float* noise, float sqrt_re
 /* flow matching Euler + CFG (transport/integrators.py:101-120, dit/dit_i23d.py:155-168):
  * v[2B] = [cond ; uncond]; x[2B] (both halves updated identically): x += dt * (vu + s*(vc - vu))       */
 int ln3d_flow_euler_step(float* x2, const float* v2, float dt, float cfg_scale, int64_t n_half, void* stream);
+/* PixArt shared adaLN (dit/dit_models_xformers.py:518-519): out[l,b,:] = tables[l,:] + t0[b,:], W = 6*D */
+int ln3d_add_table_rows(const float* t0, const float* tables, float* out, int layers, int B, int64_t W, void* stream);
+/* forward_with_cfg (dit/dit_i23d.py:155-168): v[2B] = [cond ; uncond] -> both halves = uncond + s*(cond-uncond) */
+int ln3d_cfg_combine_dup(float* v2, float cfg_scale, int64_t n_half, void* stream);
 /* y = a*x + b*y (axpby, f32) - Heun / generic combinations */
 int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 

@@ -327,6 +327,35 @@ extern "C" int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n,
   return ln3d_check_launch();
 }
 
+// out[l, b, :] = tables[l, :] + t0[b, :]   (PixArt shared adaLN: scale_shift_table[None] + t.reshape(B,6,D),
+// dit/dit_models_xformers.py:518-519) for all layers at once
+__global__ void add_table_rows_kernel(const float* t0, const float* tables, float* out, int B, int64_t W, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t w = i % W, lb = i / W, b = lb % B, l = lb / B;
+  out[i] = tables[l * W + w] + t0[b * W + w];
+}
+extern "C" int ln3d_add_table_rows(const float* t0, const float* tables, float* out, int layers, int B, int64_t W, void* stream) {
+  if (!t0 || !tables || !out) return LN3D_ERR_BAD_ARG;
+  const int64_t total = (int64_t)layers * B * W;
+  hipLaunchKernelGGL(add_table_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t0, tables, out, B, W, total);
+  return ln3d_check_launch();
+}
+
+// forward_with_cfg (dit/dit_i23d.py:155-168): v[2B] = [cond ; uncond] -> both halves = uncond + s*(cond - uncond)
+__global__ void cfg_combine_dup_kernel(float* v2, float scale, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float c = v2[i], u = v2[n + i];
+  const float h = u + scale * (c - u);
+  v2[i] = h; v2[n + i] = h;
+}
+extern "C" int ln3d_cfg_combine_dup(float* v2, float cfg_scale, int64_t n_half, void* stream) {
+  if (!v2 || n_half <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cfg_combine_dup_kernel, dim3((unsigned)((n_half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v2, cfg_scale, n_half);
+  return ln3d_check_launch();
+}
+
 // ------------------------------------------------------------------ misc
 extern "C" const char* ln3d_strerror(int code) {
   switch (code) {

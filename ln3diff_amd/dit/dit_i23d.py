@@ -1,0 +1,190 @@
+"""DiT_I23D_PixelArt (image -> tri-plane latent flow-matching denoiser) on the HIP kernels.
+
+Surface of the reference's dit/dit_i23d.py:173-291 (`DiT_models['DiT-PixArt-L/2'](input_size, num_classes,
+learn_sigma, in_channels, context_dim, roll_out, pooling_ctx_dim)`, `forward(x, timesteps, context)` with the sgm
+context dict {'crossattn': [B,256,2048] = CLIP(1024) || DINO(1024), 'vector': [B,768]}, `forward_with_cfg`) and its
+state-dict keys.  Blocks are ImageCondDiTBlockPixelArtRMSNorm (dit/dit_models_xformers.py:481-539,604-618):
+ONE shared adaLN whose output is added to a per-block learned scale_shift_table, RMSNorm pre-norms, self-attention over
+[modulated x (768) ; projected DINO tokens (256)] with per-head RMSNorm on q/k, cross-attention to the RMS-normed CLIP
+tokens, erf-GELU MLP; T2IFinalLayer.  Everything that depends only on the conditioning image (cap_embedder token,
+DINO projection, normed CLIP tokens, every block's cross K / V^T) is computed once per prompt (prepare_context).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
+                                  self_attention_hip)
+from .dit_trilatent import DiT, DiT_TriLatent
+
+
+class DiT_I23D_PixelArt(DiT_TriLatent):
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4,
+                 class_dropout_prob=0.1, num_classes=1000, learn_sigma=True, mixing_logit_init=-3, mixed_prediction=True,
+                 context_dim=False, pooling_ctx_dim=768, roll_out=False, vit_blk=ImageCondDiTBlockPixelArtRMSNorm,
+                 final_layer_blk=T2IFinalLayer):
+        super().__init__(input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio,
+                         class_dropout_prob, num_classes, learn_sigma, mixing_logit_init, mixed_prediction, context_dim,
+                         roll_out, vit_blk, T2IFinalLayer)
+        self.clip_ctx_dim = 1024
+        del self.clip_text_proj
+        self.dino_proj = CaptionEmbedder(context_dim, hidden_size)
+        self.clip_spatial_proj = CaptionEmbedder(1024, hidden_size)     # present in the checkpoint, unused by forward
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.cap_embedder = nn.Sequential(nn.LayerNorm(pooling_ctx_dim), nn.Linear(pooling_ctx_dim, hidden_size))
+        self.attention_y_norm = RMSNormP(1024)
+        self.pooling_ctx_dim = pooling_ctx_dim
+
+    def _ensure_packed(self, device):
+        if self._packed is not None and self._packed['device'] == device:
+            return
+        from .dit_models_xformers import Workspace
+        D = self.embed_dim
+        P = {'device': device}
+        P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
+        P['pe_b'] = f32(self.x_embedder.proj.bias, device)
+        P['pos'] = f32(self.pos_embed[0], device)
+        P['t_w0'], P['t_b0'] = bf16(self.t_embedder.mlp[0].weight, device), f32(self.t_embedder.mlp[0].bias, device)
+        P['t_w2'], P['t_b2'] = bf16(self.t_embedder.mlp[2].weight, device), f32(self.t_embedder.mlp[2].bias, device)
+        P['ada_w'], P['ada_b'] = bf16(self.adaLN_modulation[1].weight, device), f32(self.adaLN_modulation[1].bias, device)
+        P['cap_ln_w'], P['cap_ln_b'] = f32(self.cap_embedder[0].weight, device), f32(self.cap_embedder[0].bias, device)
+        P['cap_w'], P['cap_b'] = bf16(self.cap_embedder[1].weight, device), f32(self.cap_embedder[1].bias, device)
+        P['ynorm_w'] = f32(self.attention_y_norm.weight, device)
+        dp = self.dino_proj.y_proj
+        P['d_w1'], P['d_b1'] = bf16(dp.fc1.weight, device), f32(dp.fc1.bias, device)
+        P['d_w2'], P['d_b2'] = bf16(dp.fc2.weight, device), f32(dp.fc2.bias, device)
+        P['sst'] = f32(torch.stack([b.scale_shift_table.reshape(-1) for b in self.blocks], 0), device)   # [depth, 6D]
+        blks = []
+        for b in self.blocks:
+            q = {}
+            q['n1'], q['n2'] = f32(b.norm1.weight, device), f32(b.norm2.weight, device)
+            q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
+            q['qn'], q['kn'] = f32(b.attn.q_norm.weight, device), f32(b.attn.k_norm.weight, device)
+            q['proj_w'], q['proj_b'] = bf16(b.attn.proj.weight, device), f32(b.attn.proj.bias, device)
+            q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
+            q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
+            q['cqn'], q['ckn'] = f32(b.cross_attn.q_norm.weight, device), f32(b.cross_attn.k_norm.weight, device)
+            q['co_w'], q['co_b'] = bf16(b.cross_attn.to_out[0].weight, device), f32(b.cross_attn.to_out[0].bias, device)
+            q['fc1_w'], q['fc1_b'] = bf16(b.mlp.mlp[0].weight, device), f32(b.mlp.mlp[1].bias, device)
+            q['fc2_w'], q['fc2_b'] = bf16(b.mlp.mlp[2].weight, device), f32(b.mlp.mlp[3].bias, device)
+            blks.append(q)
+        P['blocks'] = blks
+        P['fin_w'], P['fin_b'] = f32(self.final_layer.linear.weight, device), f32(self.final_layer.linear.bias, device)
+        P['fin_sst'] = f32(self.final_layer.scale_shift_table, device)          # [2, D]
+        P['zeros'] = torch.zeros(max(D, self.pooling_ctx_dim), device=device)
+        self._packed = P
+        self._ws = Workspace(device)
+
+    @torch.no_grad()
+    def prepare_context(self, context):
+        ca, vec = context['crossattn'], context['vector']
+        dev = ca.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        Bn, Lc, _ = ca.shape
+        D, H, C1 = self.embed_dim, self.num_heads, self.clip_ctx_dim
+        # pooled token: LayerNorm(affine, eps 1e-5) -> Linear   (dit_i23d.py:211-217,245)
+        vn = ws.get('cap_vn', (Bn, self.pooling_ctx_dim), torch.bfloat16)
+        ops.norm_modulate(vec.contiguous().float(), vn, Bn, self.pooling_ctx_dim, kind=0, eps=1e-5, weight=P['cap_ln_w'],
+                          shift=P['cap_ln_b'], scale=P['zeros'], mod_rows=1 << 30, mod_ld=0)
+        cls = torch.empty(Bn, D, device=dev, dtype=torch.float32)
+        ops.gemm(vn, P['cap_w'], P['cap_b'], ops.EPI_F32, cls)
+        # CLIP tokens: RMSNorm once (dit_i23d.py:247); DINO tokens: tanh-GELU MLP
+        clip_n = ws.get('clip_n', (Bn * Lc, C1), torch.bfloat16)
+        ops.norm_modulate(ca[..., :C1].contiguous().float(), clip_n, Bn * Lc, C1, kind=1, eps=1e-5, weight=P['ynorm_w'])
+        dino_in = ws.get('dino_in', (Bn * Lc, ca.shape[-1] - C1), torch.bfloat16)
+        ops.cast_bf16(ca[..., C1:].contiguous().float(), dino_in)
+        d1 = ws.get('dino_h', (Bn * Lc, D), torch.bfloat16)
+        ops.gemm(dino_in, P['d_w1'], P['d_b1'], ops.EPI_GELU_TANH, d1)
+        dino = torch.empty(Bn, Lc, D, device=dev, dtype=torch.bfloat16)
+        ops.gemm(d1, P['d_w2'], P['d_b2'], ops.EPI_BF16, dino)
+        lpad = (Lc + 63) // 64 * 64
+        k_all = torch.zeros(self.depth, Bn, H, lpad, 64, dtype=torch.bfloat16, device=dev)
+        vt_all = torch.zeros(self.depth, Bn, H, 64, lpad, dtype=torch.bfloat16, device=dev)
+        for i, q in enumerate(P['blocks']):
+            ops.gemm(clip_n, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad,
+                     heads=H, head_dim=64, transpose_mask=0b10)
+            ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
+        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': dino}
+
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None, **kwargs):
+        if get_attr != '':
+            return getattr(self, get_attr)
+        if not x.is_cuda:
+            raise RuntimeError("ln3diff_amd.DiT_I23D_PixelArt runs on the HIP device only (no CPU fallback)")
+        dev = x.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        cc = context_cache if context_cache is not None else self.prepare_context(context)
+        D, H, depth = self.embed_dim, self.num_heads, self.depth
+        Bn, Bx = timesteps.shape[0], x.shape[0]
+        assert cc['Bn'] == Bn
+        S, p, C = self.input_size, self.patch_size, self.in_channels
+        N = 3 * (S // p) ** 2
+        Ld = cc['dino'].shape[1]
+        NA = N + Ld
+        M = Bn * N
+
+        t32 = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        tf = ws.get('tfreq', (Bn, 256), torch.bfloat16)
+        ops.timestep_embedding(t32, tf, Bn, 256)
+        th = ws.get('th', (Bn, D), torch.bfloat16)
+        ops.gemm(tf, P['t_w0'], P['t_b0'], ops.EPI_SILU, th)
+        temb = ws.get('temb', (Bn, D), torch.float32)
+        ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32, temb)
+        tsum = ws.get('tsum', (Bn, D), torch.float32)                  # t = t_embedder(timesteps) + cap token
+        tsilu = ws.get('tsilu', (Bn, D), torch.bfloat16)
+        ops.add_act_cast(temb, cc['cls'], tsilu, tsum, Bn * D, 1)
+        t0 = ws.get('t0', (Bn, 6 * D), torch.float32)
+        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, t0)
+        mod = ws.get('modb', (depth, Bn, 6 * D), torch.float32)
+        ops.add_table_rows(t0, P['sst'], mod, depth, Bn, 6 * D)
+
+        xt = ws.get('x', (M, D), torch.float32)
+        ops.patch_embed(x.contiguous().float(), in_scale, P['pe_w'], P['pe_b'], P['pos'], xt, Bx, Bn, C, S, p, D)
+        ha = ws.get('ha', (Bn, NA, D), torch.bfloat16)
+        if getattr(self, '_ha_src', None) is not cc['dino'] or getattr(self, '_ha_buf', None) is not ha:
+            ha[:, N:].copy_(cc['dino'])                                # appended DINO tokens: constant per prompt, and the
+            self._ha_src, self._ha_buf = cc['dino'], ha                # norm kernel only ever writes rows < N of each sample
+        hb = ws.get('h', (M, D), torch.bfloat16)
+        xb = ws.get('xb', (M, D), torch.bfloat16)
+        qc = ws.get('qc', (Bn, H, N, 64), torch.bfloat16)
+        oc = ws.get('oc', (M, H * 64), torch.bfloat16)
+        f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
+        ld = 6 * D
+        for i, q in enumerate(P['blocks']):
+            mi = mod[i]
+            ops.norm_modulate(xt, ha, M, D, kind=1, eps=1e-5, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
+                              mod_ld=ld, rows_in=N, rows_out=NA)
+            ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
+            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld)
+            ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
+            ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
+            ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
+            ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
+            ops.norm_modulate(xt, hb, M, D, kind=1, eps=1e-5, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],
+                              mod_rows=N, mod_ld=ld)
+            ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+            ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=mi[:, 5 * D:], gate_rows=N, gate_ld=ld)
+        out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)
+        ops.final_layer(xt, tsum, tsum, D, P['fin_sst'][0], P['fin_sst'][1], P['fin_w'], P['fin_b'], out, Bn,
+                        self.out_channels, S, p, D)
+        return out
+
+    @torch.no_grad()
+    def forward_with_cfg(self, x, t, context=None, cfg_scale=4.0, context_cache=None, **kw):
+        eps = self.forward(x, t, context, context_cache=context_cache)
+        ops.cfg_combine_dup(eps, float(cfg_scale))
+        return eps
+
+
+def DiT_L_Pixelart_2(**kwargs):
+    return DiT_I23D_PixelArt(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_B_Pixelart_2(**kwargs):
+    return DiT_I23D_PixelArt(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
+
+
+DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2}

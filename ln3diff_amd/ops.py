@@ -149,3 +149,11 @@ def patch_embed_triplane(latent, w, bias, out_silu, out_raw, B, Cg, S, p, D):
 
 def tile_rows(x, y, per, reps):
     L.check(L.lib().ln3d_tile_rows(_p(x), _p(y), C.c_int64(per), reps, _stream()), "tile_rows")
+
+
+def add_table_rows(t0, tables, out, layers, B, W):
+    L.check(L.lib().ln3d_add_table_rows(_p(t0), _p(tables), _p(out), layers, B, C.c_int64(W), _stream()), "add_table_rows")
+
+
+def cfg_combine_dup(v2, cfg_scale):
+    L.check(L.lib().ln3d_cfg_combine_dup(_p(v2), C.c_float(cfg_scale), C.c_int64(v2.numel() // 2), _stream()), "cfg_combine_dup")
