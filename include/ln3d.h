@@ -58,7 +58,7 @@ typedef struct {
   const float* gate; int gate_rows; int64_t gate_ld;
   /* HEADS: column n -> which = n / (heads*head_dim), h, d; row m -> b = m / tokens, t = m % tokens.
    *   which w writes out{w}: layout [B, heads, tok_pad, head_dim] if !(transpose_mask>>w & 1)
-   *   else [B, heads, head_dim, tok_pad] (V^T for the attention kernel's PV operand).       */
+   *   else [B, heads, head_dim, tok_pad] with tokens key-permuted inside 16-groups (V^T for ln3d_attention_bf16). */
   int tokens; int tok_pad; int heads; int head_dim; int transpose_mask;
 } ln3d_gemm_args;
 
@@ -66,7 +66,9 @@ int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);
 
 /* ---------------------------------------------------------------- fused attention
  * O[b, q, h*Dh + d] = softmax_k(scale * Q.K^T) V, bf16 in/out, fp32 softmax, MFMA 32x32x16.
- *   Q  : bf16 [B, H, Nq_pad, Dh]   K : bf16 [B, H, Nk_pad, Dh]   Vt : bf16 [B, H, Dh, Nk_pad]
+ *   Q  : bf16 [B, H, Nq_pad, Dh]   K : bf16 [B, H, Nk_pad, Dh]   Vt : bf16 [B, H, Dh, Nk_pad] with the keys of every
+ *   16-group stored in the order [0-3, 8-11, 4-7, 12-15] (position p holds key p with bits 2,3 swapped) - the layout
+ *   ln3d_gemm_bf16's LN3D_EPI_HEADS epilogue emits for transposed outputs.
  *   O  : bf16 [B, Nq, ldo]  (only rows q < Nq written).  Keys k >= Nk are masked; Nk_pad % 64 == 0 and
  *   the padded K / Vt entries must be finite (zero).  Dh in {64, 128}.
  * Replaces xformers.ops.memory_efficient_attention at vit/vision_transformer.py:118,

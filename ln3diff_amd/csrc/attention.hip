@@ -1,20 +1,15 @@
 // Fused (flash-style) attention for gfx950: O = softmax(scale * Q K^T) V, bf16 in/out, fp32 softmax.
 //
 // Design (MI355X-first):
-//  * v_mfma_f32_32x32x16_bf16, wave64.  One workgroup = 4 waves = 128 query rows of one (batch, head);
-//    each wave owns 32 query rows, K/V are streamed in 64-key blocks through LDS shared by the 4 waves.
-//  * "Swapped" products so that every softmax statistic is lane-local:
+//  * v_mfma_f32_32x32x16_bf16, wave64, "swapped" products so that every softmax statistic is lane-local:
 //       S^T[key, q] = K . Q^T      (A = K tile rows, B = Q fragment held in VGPRs for the whole kernel)
 //       O^T[d,  q]  = V^T . P^T    (A = V^T tile rows, B = P converted to bf16 in registers)
-//    In the 32x32 accumulator layout a lane owns ONE query column (lane&31) and 16 of the 32 key rows,
-//    so row-max / row-sum are 32 in-register ops + one exchange with lane^32, the online-softmax
-//    rescale factor is a per-lane scalar, and P feeds the second MFMA directly as its B operand:
-//    the k-index permutation of the accumulator layout is absorbed by reading the V^T A-operand with
-//    the same permutation (two ds_read_b64 per fragment) - no LDS round trip for P, no transposes.
-//  * V arrives already transposed ([B,H,Dh,Nk_pad]) from the QKV GEMM epilogue, so both LDS tiles are
-//    contraction-contiguous.  LDS rows are padded (K: 144 B for Dh=64, V^T: 136 B) which makes the
-//    ds_read_b128 / ds_read_b64 fragment reads bank-conflict free.  Tiles are double-buffered; the
-//    next block's global loads are issued before the MFMA work of the current block.
+//    In the 32x32 accumulator layout a lane owns ONE query column (lane&31) and 16 of the 32 key rows, so row-max /
+//    row-sum are 32 in-register ops + one exchange with lane^32, the online-softmax rescale factor is a per-lane
+//    scalar, and P feeds the second MFMA directly as its B operand (no LDS round trip, no transposes): the key
+//    permutation of the accumulator layout is baked into the V^T memory layout (see attn_kernel).
+//  * softmax in the log2 domain: one FMA + one v_exp_f32 per score; the O rescale is skipped, wave-uniformly and
+//    exactly, when no row maximum moved.
 #include <type_traits>
 #include "common.h"
 #include "../../include/ln3d.h"
@@ -27,32 +22,41 @@ struct AttnP {
 };
 
 #define KVB 64
-#define VROWB 136  // V^T tile row: 64 keys * 2 B + 8 pad
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
-  constexpr int KROWB = DH * 2 + 16;          // K tile row bytes (padded)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// One workgroup = 8 waves = 256 query rows of one (batch, head): K / V^T stream from L2 ONCE per 256 queries
+// (the stream, not the MFMA, bounds this kernel: K+V of one head is 196 KB against 50 MFLOP per 256 queries).
+// K / V^T blocks of 64 keys are filled by LDS-DMA (global_load_lds_dwordx4) into an NST-deep ring; counted vmcnt +
+// raw s_barrier keep NST-2 blocks in flight across the per-block barrier.  LDS rows are unpadded and XOR-swizzled at
+// 16-B granularity (swizzle on the DMA source address and on the ds_read_b128 side): conflict-free b128 reads.
+// V^T arrives from the QKV GEMM epilogue with the keys of every 16-group permuted to [0-3, 8-11, 4-7, 12-15], which is
+// the order the S^T accumulator layout hands P to the second MFMA: the PV A-operand is one aligned 16-B read.
+// OCC = waves per SIMD the register allocation is bounded for: 4 (128 VGPRs, two workgroups per CU) for long key
+// sequences where latency hiding matters; 2 (256 VGPRs, no spills in the masked tail block) for short ones (cross-attention).
+template <int DH, int OCC>
+__global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
+  constexpr int NST = DH == 64 ? 4 : 3;           // ring depth
+  constexpr int KROWB = DH * 2;                   // K tile row bytes
   constexpr int KTILE = KVB * KROWB;
-  constexpr int VTILE = DH * VROWB;
-  constexpr int NDS = DH / 16;                // MFMA k-steps over head dim
-  constexpr int NDT = DH / 32;                // 32-row d-tiles of O^T
-  constexpr int KCH = DH / 8;                 // 16-B chunks per K row
-  constexpr int KLD = KVB * KCH / 256;        // K chunks per thread   (2 for DH=64, 4 for 128)
-  constexpr int VLD = DH * 8 / 256;           // V^T chunks per thread (2 / 4)
+  constexpr int VTILE = DH * 128;                 // V^T tile: DH rows x 64 keys
+  constexpr int STAGEB = KTILE + VTILE;
+  constexpr int NDS = DH / 16, NDT = DH / 32;
+  constexpr int LPW = DH / 64;                    // DMA instructions per wave per tile (K and V^T each)
+  constexpr int KCH = DH / 8;                     // 16-B chunks per K row (8 or 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kbuf = smem;                          // 2 x KTILE
-  char* vbuf = smem + 2 * KTILE;              // 2 x VTILE
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int q0 = blockIdx.x * 256 + wid * 32;
 
   const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
   const bf16_t* Kg = p.K + (int64_t)bh * p.Nk_pad * DH;
   const bf16_t* Vg = p.Vt + (int64_t)bh * DH * p.Nk_pad;
 
-  // Q fragments (B operand of S^T = K.Q^T): lane (q = l31, hi) holds d = 16*ds + 8*hi + 0..7
   bf16x8 qf[NDS];
   {
     int qr = q0 + l31; qr = qr < p.Nq ? qr : p.Nq - 1;
@@ -61,72 +65,60 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     for (int ds = 0; ds < NDS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
   }
 
+  // DMA source addressing: wave-instruction j of a tile writes LDS bytes [1024 j, 1024 j + 1024)
+  const bf16_t* ksrc[LPW]; const bf16_t* vsrc[LPW];
+  int kdst[LPW], vdst[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int j = wid + 8 * i;
+    const int krow = j * (1024 / KROWB) + lane / KCH, kcp = lane % KCH;
+    const int kkey = DH == 64 ? ((krow >> 1) & 7) : (krow & 15);
+    ksrc[i] = Kg + (int64_t)krow * DH + ((kcp ^ kkey) * 8);
+    kdst[i] = j * 1024;
+    const int vrow = j * 8 + (lane >> 3), vcp = lane & 7;
+    vsrc[i] = Vg + (int64_t)vrow * p.Nk_pad + ((vcp ^ ((vrow >> 1) & 7)) * 8);
+    vdst[i] = KTILE + j * 1024;
+  }
+#define A_ISSUE(kbv)                                                                                          \
+  {                                                                                                           \
+    const int kb_i_ = (kbv);                                                                                  \
+    char* sb_ = smem + (kb_i_ % NST) * STAGEB;                                                                \
+    _Pragma("unroll") for (int ii_ = 0; ii_ < LPW; ++ii_) {                                                   \
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(ksrc[ii_] + (int64_t)kb_i_ * KVB * DH), (lds_void_t*)(sb_ + kdst[ii_]), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(vsrc[ii_] + kb_i_ * KVB), (lds_void_t*)(sb_ + vdst[ii_]), 16, 0, 0); \
+    }                                                                                                         \
+  }
+
   f32x16 oacc[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
   float m_run = -3.0e38f, l_run = 0.f;
-
   const int nkb = (p.Nk + KVB - 1) / KVB;
 
-  // staging maps
-  int k_row[KLD], k_c[KLD], v_row[VLD], v_c[VLD];
-#pragma unroll
-  for (int i = 0; i < KLD; ++i) { const int id = tid + 256 * i; k_row[i] = id / KCH; k_c[i] = id % KCH; }
-#pragma unroll
-  for (int i = 0; i < VLD; ++i) { const int id = tid + 256 * i; v_row[i] = id >> 3; v_c[i] = id & 7; }
+  // fragment read offsets
+  const int kkey_r = DH == 64 ? ((l31 >> 1) & 7) : (l31 & 15);      // key rows kt*32 + l31: kt*32 does not change the key
+  const int k_off = l31 * KROWB;
+  const int vkey_r = (l31 >> 1) & 7;
+  const int v_off = KTILE + l31 * 128;
 
-  // in-flight tile lives in named VGPRs (arrays end up in scratch around the sched barriers)
-  uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
-  kr2 = kr3 = vr2 = vr3 = make_uint4(0, 0, 0, 0);
-#define LN3D_KLOAD(i, dst) dst = *reinterpret_cast<const uint4*>(Kg + (int64_t)(kb_ * KVB + k_row[i]) * DH + k_c[i] * 8)
-#define LN3D_VLOAD(i, dst) dst = *reinterpret_cast<const uint4*>(Vg + (int64_t)v_row[i] * p.Nk_pad + kb_ * KVB + v_c[i] * 8)
-#define LN3D_KSTORE(i, src) *reinterpret_cast<uint4*>(kdst + k_row[i] * KROWB + k_c[i] * 16) = src
-#define LN3D_VSTORE(i, src)                                                        \
-  {                                                                                \
-    char* d_ = vdst + v_row[i] * VROWB + v_c[i] * 16; /* 8-B aligned only */       \
-    *reinterpret_cast<uint2*>(d_) = make_uint2(src.x, src.y);                      \
-    *reinterpret_cast<uint2*>(d_ + 8) = make_uint2(src.z, src.w);                  \
-  }
-#define LN3D_GLOAD(kbv)                                     \
-  {                                                         \
-    const int kb_ = (kbv);                                  \
-    LN3D_KLOAD(0, kr0); LN3D_KLOAD(1, kr1);                 \
-    if constexpr (KLD > 2) { LN3D_KLOAD(2, kr2); LN3D_KLOAD(3, kr3); } \
-    LN3D_VLOAD(0, vr0); LN3D_VLOAD(1, vr1);                 \
-    if constexpr (VLD > 2) { LN3D_VLOAD(2, vr2); LN3D_VLOAD(3, vr3); } \
-  }
-#define LN3D_LSTORE(bufv)                                   \
-  {                                                         \
-    char* kdst = kbuf + (bufv) * KTILE; char* vdst = vbuf + (bufv) * VTILE; \
-    LN3D_KSTORE(0, kr0); LN3D_KSTORE(1, kr1);               \
-    if constexpr (KLD > 2) { LN3D_KSTORE(2, kr2); LN3D_KSTORE(3, kr3); } \
-    LN3D_VSTORE(0, vr0); LN3D_VSTORE(1, vr1);               \
-    if constexpr (VLD > 2) { LN3D_VSTORE(2, vr2); LN3D_VSTORE(3, vr3); } \
-  }
-
-  auto process = [&](int kb, int buf, auto tail_tag) {
+  auto process = [&](int kb, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const char* kt_ = kbuf + buf * KTILE;
-    const char* vt_ = vbuf + buf * VTILE;
-
-    // ---- S^T = K . Q^T  : two 32-key tiles
+    const char* sb = smem + (kb % NST) * STAGEB;
     f32x16 st[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_ + (kt * 32 + l31) * KROWB + ds * 32 + hi * 16);
+    for (int ds = 0; ds < NDS; ++ds) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off + kt * 32 * KROWB + (((2 * ds + hi) ^ kkey_r) << 4));
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], st[kt], 0, 0, 0);
       }
     }
-
-    // ---- online softmax in the log2 domain (lane-local over its 2x16 keys, one exchange with lane^32):
-    //      p = exp2(s*c - m) as one FMA + one v_exp per element; the O rescale is skipped (wave-uniformly) when no
-    //      row maximum moved, which is exact (alpha == 1), not an approximation.
     if constexpr (TAIL) {
       const int key_base = kb * KVB + 4 * hi;
 #pragma unroll
@@ -143,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);     // scale > 0
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
     if (!__all(m_new == m_run)) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -163,8 +155,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         psum += pv;
       }
     l_run += psum;
-
-    // ---- P^T as B operand: step s uses tile s>>1, regs 8*(s&1)..+7  <->  keys 16s + 4hi + (j&3) + 8(j>>2)
     bf16x8 pb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -174,38 +164,38 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         cv.u[jj] = pack2bf(st[s >> 1][8 * (s & 1) + 2 * jj], st[s >> 1][8 * (s & 1) + 2 * jj + 1]);
       pb[s] = cv.v;
     }
-
-    // ---- O^T += V^T . P^T
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const char* vrow = vt_ + (dt * 32 + l31) * VROWB + hi * 8;
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        union { uint2 h[2]; bf16x8 v; } vf;
-        vf.h[0] = *reinterpret_cast<const uint2*>(vrow + s * 32);
-        vf.h[1] = *reinterpret_cast<const uint2*>(vrow + s * 32 + 16);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pb[s], oacc[dt], 0, 0, 0);
+      for (int dt = 0; dt < NDT; ++dt) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + v_off + dt * 32 * 128 + (((2 * s + hi) ^ vkey_r) << 4));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], oacc[dt], 0, 0, 0);
       }
     }
   };
 
-  LN3D_GLOAD(0);
-  LN3D_LSTORE(0);
-  __syncthreads();
-
-  for (int kb = 0; kb + 1 < nkb; ++kb) {
-    const int buf = kb & 1;
-    LN3D_GLOAD(kb + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    process(kb, buf, std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
-    LN3D_LSTORE(buf ^ 1);
-    __syncthreads();
+  // prologue: up to NST-1 blocks in flight
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < nkb) A_ISSUE(i);
+#define A_WAIT(kbv)                                                                                         \
+  {                                                                                                           \
+    const int ahead_ = min(NST - 2, nkb - 1 - (kbv));   /* blocks that may stay in flight while block kb is consumed */ \
+    if (ahead_ >= 2) { if constexpr (LPW == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
+    else if (ahead_ == 1) { if constexpr (LPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 /* this wave's LDS reads of block kb-1 are complete */  \
+    __builtin_amdgcn_s_barrier();                                                                             \
+    if ((kbv) + NST - 1 < nkb) A_ISSUE((kbv) + NST - 1); /* ring slot of block kb-1: every wave is past it */   \
   }
-  if ((p.Nk & (KVB - 1)) != 0) process(nkb - 1, (nkb - 1) & 1, std::true_type{});
-  else process(nkb - 1, (nkb - 1) & 1, std::false_type{});
+  for (int kb = 0; kb + 1 < nkb; ++kb) {
+    A_WAIT(kb);
+    process(kb, std::false_type{});
+  }
+  A_WAIT(nkb - 1);
+  if ((p.Nk & (KVB - 1)) != 0) process(nkb - 1, std::true_type{});
+  else process(nkb - 1, std::false_type{});
 
-  // ---- epilogue: O[b, q, h*DH + d] = O^T[d, q] / l
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
@@ -224,17 +214,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   }
 }
 
-template <int DH>
+template <int DH, int OCC>
 static int launch_attn(const AttnP& p, hipStream_t s) {
-  constexpr int LDS = 2 * (KVB * (DH * 2 + 16)) + 2 * (DH * VROWB);
+  constexpr int NST = DH == 64 ? 4 : 3;
+  constexpr int LDS = NST * (KVB * DH * 2 + DH * 128);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH, OCC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  dim3 grid((p.Nq + 127) / 128, p.B * p.H);
-  hipLaunchKernelGGL(attn_kernel<DH>, grid, dim3(256), LDS, s, p);
+  dim3 grid((p.Nq + 255) / 256, p.B * p.H);
+  hipLaunchKernelGGL((attn_kernel<DH, OCC>), grid, dim3(512), LDS, s, p);
   return ln3d_check_launch();
 }
 
@@ -247,8 +238,8 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   p.ldo = a->ldo;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  if (a->Dh == 64) return launch_attn<64>(p, s);
-  if (a->Dh == 128) return launch_attn<128>(p, s);
+  if (a->Dh == 64) return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
+  if (a->Dh == 128) return launch_attn<128, 2>(p, s);
   return LN3D_ERR_UNSUPPORTED;
 }
 

@@ -80,7 +80,10 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
       uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
       *reinterpret_cast<uint2*>(dst + (bh * p.tok_pad + t) * p.head_dim + d) = o;
     } else {
-      bf16_t* q = dst + (bh * p.head_dim + d) * p.tok_pad + t;
+      // V^T: tokens of every 16-group stored in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of t swapped) - the
+      // order in which the attention kernel's S^T accumulator hands P to the PV MFMA (csrc/attention.hip)
+      const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+      bf16_t* q = dst + (bh * p.head_dim + d) * p.tok_pad + tp;
       q[0] = f2bf(v0); q[p.tok_pad] = f2bf(v1); q[2 * (int64_t)p.tok_pad] = f2bf(v2); q[3 * (int64_t)p.tok_pad] = f2bf(v3);
     }
   }

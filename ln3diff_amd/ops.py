@@ -157,3 +157,11 @@ def add_table_rows(t0, tables, out, layers, B, W):
 
 def cfg_combine_dup(v2, cfg_scale):
     L.check(L.lib().ln3d_cfg_combine_dup(_p(v2), C.c_float(cfg_scale), C.c_int64(v2.numel() // 2), _stream()), "cfg_combine_dup")
+
+
+def vt_key_order(n_pad, device=None):
+    """Index map of the V^T layout consumed by ln3d_attention_bf16: position p of every 16-key group holds key
+    perm(p) with bits 2 and 3 swapped ([0-3, 8-11, 4-7, 12-15]).  ln3d_gemm_bf16's HEADS epilogue writes this layout
+    itself; this helper exists for callers (tests, op-level bindings) that build V^T by hand: vt_perm = vt[..., idx]."""
+    t = torch.arange(n_pad, device=device)
+    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)

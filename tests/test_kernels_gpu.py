@@ -109,8 +109,10 @@ def test_gemm_heads_split(ops):
     ops.gemm(xb, wb, b, ops.EPI_HEADS, q, k, vt, M=B * T, tokens=T, tok_pad=tp, heads=H, head_dim=Dh, transpose_mask=0b100)
     assert rel_l2(q[:, :, :T].float(), ref[:, :, 0].permute(0, 2, 1, 3)) < 4e-3
     assert rel_l2(k[:, :, :T].float(), ref[:, :, 1].permute(0, 2, 1, 3)) < 4e-3
-    assert rel_l2(vt[:, :, :, :T].float(), ref[:, :, 2].permute(0, 2, 3, 1)) < 4e-3
-    assert float(q[:, :, T:].abs().max()) == 0 and float(vt[:, :, :, T:].abs().max()) == 0
+    vt_nat = torch.zeros_like(vt)
+    vt_nat[..., ops.vt_key_order(tp, dev)] = vt                 # undo the key permutation of the V^T layout
+    assert rel_l2(vt_nat[:, :, :, :T].float(), ref[:, :, 2].permute(0, 2, 3, 1)) < 4e-3
+    assert float(q[:, :, T:].abs().max()) == 0 and float(vt_nat[:, :, :, T:].abs().max()) == 0
 
 
 def _attn_ref(q, k, v, scale):
@@ -134,7 +136,7 @@ def test_attention(ops, B, H, Nq, Nk, Dh):
     if Nk > 128:
         k[:, :, Nk - 5] = q[:, :, 3] * 4.0
     qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
-    vt = vb.transpose(-1, -2).contiguous()
+    vt = vb.transpose(-1, -2)[..., ops.vt_key_order(nkp, dev)].contiguous()      # key-permuted V^T layout (ABI)
     out = torch.empty(B, Nq, H * Dh, device=dev, dtype=torch.bfloat16)
     ops.attention(qb, kb, vt, out, B, H, Nq, nqp, Nk, nkp, Dh)
     ref = _attn_ref(qb[:, :, :Nq], kb[:, :, :Nk], vb[:, :, :Nk], Dh ** -0.5)       # [B,H,Nq,Dh]
