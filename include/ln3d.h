@@ -144,6 +144,10 @@ int ln3d_edm_euler_step(float* x, const float* eps2, float sigma, float sigma_ne
  * 252-271, 535-545): x <- c1*x0 + c2*x + nonzero*exp(0.5*logvar)*noise, x0 = a*x - b*eps (opt. clip)  */
 int ln3d_ddpm_step(float* x, const float* eps, const float* noise, float sqrt_recip, float sqrt_recipm1,
                    float coef1, float coef2, float sigma_t, int clip, int64_t n, void* stream);
+/* GaussianDiffusion.ddim_sample (guided_diffusion/gaussian_diffusion.py:729-866): eps = eu + s*(ec-eu) (eps_c NULL = no CFG),
+ * x0 = a*x - b*eps, x <- sqrt(ab_prev)*x0 + coef_eps*eps + sigma*noise (noise NULL when sigma == 0 / t == 0)         */
+int ln3d_ddim_step(float* x, const float* eps_u, const float* eps_c, const float* noise, float cfg_scale, float sqrt_recip,
+                   float sqrt_recipm1, float sqrt_ab_prev, float coef_eps, float sigma, int clip, int64_t n, void* stream);
 /* flow matching Euler + CFG (transport/integrators.py:101-120, dit/dit_i23d.py:155-168):
  * v[2B] = [cond ; uncond]; x[2B] (both halves updated identically): x += dt * (vu + s*(vc - vu))       */
 int ln3d_flow_euler_step(float* x2, const float* v2, float dt, float cfg_scale, int64_t n_half, void* stream);

@@ -303,6 +303,33 @@ extern "C" int ln3d_ddpm_step(float* x, const float* eps, const float* noise, fl
   return ln3d_check_launch();
 }
 
+// DDIM step with optional CFG on eps (guided_diffusion/gaussian_diffusion.py:729-866, non-objv branch):
+// eps = eu + s*(ec - eu); x0 = a*x - b*eps (opt. clip; eps re-derived from the clipped x0 as the reference does);
+// x <- sqrt(ab_prev)*x0 + sqrt(1 - ab_prev - sigma^2)*eps + sigma*noise
+__global__ void ddim_step_kernel(float* x, const float* eu, const float* ec, const float* noise, float scale, float a, float b,
+                                 float sqrt_ab_prev, float coef_eps, float sigma, int clip, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  float e_u = eu[i], e_c = ec ? ec[i] : 0.f;
+  if (clip) {                     // p_mean_variance clips x0, then eps is re-derived per branch
+    float x0u = fminf(fmaxf(a * xv - b * e_u, -1.f), 1.f);
+    e_u = (a * xv - x0u) / b;
+    if (ec) { float x0c = fminf(fmaxf(a * xv - b * e_c, -1.f), 1.f); e_c = (a * xv - x0c) / b; }
+  }
+  const float eps = ec ? e_u + scale * (e_c - e_u) : e_u;
+  const float x0 = a * xv - b * eps;
+  x[i] = x0 * sqrt_ab_prev + coef_eps * eps + (noise ? sigma * noise[i] : 0.f);
+}
+extern "C" int ln3d_ddim_step(float* x, const float* eps_u, const float* eps_c, const float* noise, float cfg_scale,
+                              float sqrt_recip, float sqrt_recipm1, float sqrt_ab_prev, float coef_eps, float sigma, int clip,
+                              int64_t n, void* stream) {
+  if (!x || !eps_u || n <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps_u, eps_c, noise,
+                     cfg_scale, sqrt_recip, sqrt_recipm1, sqrt_ab_prev, coef_eps, sigma, clip, n);
+  return ln3d_check_launch();
+}
+
 __global__ void flow_euler_step_kernel(float* x2, const float* v2, float dt, float scale, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

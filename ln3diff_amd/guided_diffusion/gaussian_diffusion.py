@@ -82,3 +82,45 @@ class GaussianDiffusion:
             if trace is not None:
                 trace.append(x.clone())
         return x
+
+
+    @torch.no_grad()
+    def ddim_sample_loop(self, model, shape, cond=None, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, mixing_normal=False,
+                         unconditional_guidance_scale=1.0, unconditional_conditioning=None, objv_inference=False,
+                         step_noise=None, trace=None):
+        """DDIM (reference :729-866,908-1000).  cond: tensor or {'c_crossattn': tensor}; CFG batches [uncond ; cond]
+        (uncond = zeros unless given) and combines eps."""
+        assert not mixing_normal and denoised_fn is None and cond_fn is None
+        dev = torch.device(device) if device is not None else noise.device
+        x = noise.to(dev).float().clone() if noise is not None else torch.randn(*shape, device=dev)
+        B = shape[0]
+        c = cond['c_crossattn'] if isinstance(cond, dict) else cond
+        cfg = unconditional_guidance_scale != 1.0
+        net = getattr(model, 'ddp_model', model)
+        if cfg:
+            ucond = torch.zeros_like(c) if unconditional_conditioning is None else unconditional_conditioning
+            if ucond.shape[0] != B:
+                ucond = ucond.repeat_interleave(B, 0)
+            ctx = torch.cat([ucond, c], 0).to(dev)
+        else:
+            ctx = c.to(dev)
+        nb = ctx.shape[0]
+        cache = net.prepare_context(ctx)
+        t_dev = torch.empty(nb, device=dev, dtype=torch.float32)
+        f32 = lambda v: float(np.float32(v))
+        for k, i in enumerate(range(self.num_timesteps)[::-1]):
+            t_dev.fill_(self._model_t(i))
+            eps = net(x, t_dev, context_cache=cache)                    # [nb, ...] on x replicated b % B
+            ab, abp = np.float32(self.alphas_cumprod[i]), np.float32(self.alphas_cumprod_prev[i])
+            sig = np.float32(eta) * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
+            coef = np.sqrt(np.float32(1) - abp - sig ** 2)
+            z = None
+            if i != 0 and float(sig) != 0.0:
+                z = (step_noise(k).to(dev) if step_noise is not None else torch.randn(x.shape, device=dev)).float().contiguous()
+            eu, ec = (eps[:B], eps[B:]) if cfg else (eps, None)
+            ops.ddim_step(x, eu, ec, z, float(unconditional_guidance_scale), f32(self.sqrt_recip_alphas_cumprod[i]),
+                          f32(self.sqrt_recipm1_alphas_cumprod[i]), float(np.sqrt(abp)), float(coef), float(sig), clip_denoised)
+            if trace is not None:
+                trace.append(x.clone())
+        return x

@@ -165,3 +165,9 @@ def vt_key_order(n_pad, device=None):
     itself; this helper exists for callers (tests, op-level bindings) that build V^T by hand: vt_perm = vt[..., idx]."""
     t = torch.arange(n_pad, device=device)
     return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+
+
+def ddim_step(x, eps_u, eps_c, noise, cfg_scale, a, b, sqrt_ab_prev, coef_eps, sigma, clip):
+    L.check(L.lib().ln3d_ddim_step(_p(x), _p(eps_u), _p(eps_c), _p(noise), C.c_float(cfg_scale), C.c_float(a), C.c_float(b),
+                                   C.c_float(sqrt_ab_prev), C.c_float(coef_eps), C.c_float(sigma), int(clip),
+                                   C.c_int64(x.numel()), _stream()), "ddim_step")

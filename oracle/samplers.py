@@ -174,6 +174,44 @@ def ddpm_p_sample_loop(net, x, noises, cond, tables, clip_denoised=False, trace=
     return x
 
 
+def ddim_sample_loop(net, x, cond, tables, eta=0.0, cfg_scale=1.0, ucond=None, noises=None, clip_denoised=False, trace=None):
+    """GaussianDiffusion.ddim_sample_loop, non-objv branch (gaussian_diffusion.py:729-866,908-1000): CFG batch is
+    [uncond ; cond]; eps is re-derived from pred_xstart; sigma from eta; `noises[k]` = randn_like of loop iteration k."""
+    B = x.shape[0]
+    tmap = torch.tensor(tables.timestep_map)
+    acp = np.append(1.0, tables.alphas_cumprod[:-1])
+    for k, i in enumerate(range(tables.num_timesteps)[::-1]):
+        t = torch.tensor([i] * B)
+        def x0_eps(xin, tin, c):
+            tc = tmap[tin] / tables.original_num_steps
+            e = net(xin, tc, c)
+            x0 = (_extract(tables.sqrt_recip_alphas_cumprod, tin, xin.shape) * xin -
+                  _extract(tables.sqrt_recipm1_alphas_cumprod, tin, xin.shape) * e)
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)
+            return (_extract(tables.sqrt_recip_alphas_cumprod, tin, xin.shape) * xin - x0) / \
+                _extract(tables.sqrt_recipm1_alphas_cumprod, tin, xin.shape)
+        if cfg_scale == 1.0:
+            eps = x0_eps(x, t, cond)
+        else:
+            uc = torch.zeros_like(cond) if ucond is None else ucond
+            e = x0_eps(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uc, cond]))
+            eu, ec = e.chunk(2)
+            eps = eu + cfg_scale * (ec - eu)
+        x0 = (_extract(tables.sqrt_recip_alphas_cumprod, t, x.shape) * x -
+              _extract(tables.sqrt_recipm1_alphas_cumprod, t, x.shape) * eps)
+        ab = _extract(tables.alphas_cumprod, t, x.shape)
+        abp = _extract(acp, t, x.shape)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        mean = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+        nz = (t != 0).float().view(-1, *([1] * (x.ndim - 1)))
+        nse = noises[k] if noises is not None else torch.zeros_like(x)
+        x = mean + nz * sigma * nse
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
 # ------------------------------------------------------- flow matching (transport)
 def flow_ode_sample(model_fn, x, num_steps=50, method="euler", **model_kwargs):
     """transport.Sampler.sample_ode for Linear path / velocity prediction: integrate

@@ -269,7 +269,37 @@ def sec_i23d():
     save('i23d_pixart_l2', y=y_ref, t=t, manifest=manifest_json(shapes))
 
 
-SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d}
+def sec_ddim():
+    print('== DDIM (reference GaussianDiffusion.ddim_sample_loop, CFG on eps) on the tiny T23D DiT')
+    m = build_t23d(128, 2, 2)
+    sd, _ = load_synth(m, 0)
+    from guided_diffusion import gaussian_diffusion as gd
+    from guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    B = 2
+    z = synth_input('z', (B, 12, 32, 32), 41)
+    c = synth_input('c', (B, 77, 768), 41)
+
+    class Adapter:
+        def apply_model_inference(self, x, t, c, **kw):
+            return m(x, t, c['c_crossattn'] if isinstance(c, dict) else c)
+    for spec, eta, s, seed in (('ddim50', 0.0, 6.5, 3), ('ddim25', 0.5, 3.0, 5)):
+        diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, spec), betas=gd.get_named_beta_schedule('linear', 1000),
+                               model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                               loss_type=gd.LossType.MSE, rescale_timesteps=False)
+        torch.manual_seed(seed)
+        # the reference repeat_interleaves the null embedding by the batch size: it expects a batch-1 tensor
+        y_ref = diff.ddim_sample_loop(Adapter(), (B, 12, 32, 32), cond={'c_crossattn': c}, noise=z.clone(),
+                                      clip_denoised=False, device='cpu', eta=eta, unconditional_guidance_scale=s,
+                                      unconditional_conditioning=torch.zeros(1, 77, 768))
+        torch.manual_seed(seed)
+        noises = [torch.randn(B, 12, 32, 32) for _ in range(diff.num_timesteps)]
+        y_or = osamp.ddim_sample_loop(lambda x, t, cc: odit.t23d_forward(sd, x, t, cc, 2), z.clone(), c,
+                                      osamp.SpacedTables(spec), eta, s, None, noises)
+        check(f'ddim {spec} eta={eta} cfg={s}', y_or, y_ref, 2e-4)
+        save(f'ddim_tiny_{spec}', final=y_ref, eta=np.array(eta), scale=np.array(s), noise_seed=np.array(seed))
+
+
+SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim}
 
 if __name__ == '__main__':
     from make_golden_render import sec_render, sec_decoder   # noqa: E402

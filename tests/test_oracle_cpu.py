@@ -133,3 +133,15 @@ def test_oracle_decode_tiny_matches_reference_golden():
     planes = odec.vae_decode(sd, latent, 2)
     assert rel_l2(planes[:, :, ::8, ::8], g['planes_sub']) < 1e-4
     assert abs(float(planes.std()) - float(g['planes_std'])) < 1e-4
+
+
+def test_oracle_ddim_matches_reference_golden():
+    g = golden('ddim_tiny_ddim25')
+    sd = _sd_from_manifest(golden('t23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 41)
+    c = synth_input('c', (2, 77, 768), 41)
+    torch.manual_seed(int(g['noise_seed']))
+    noises = [torch.randn(2, 12, 32, 32) for _ in range(25)]
+    y = osamp.ddim_sample_loop(lambda x, t, cc: odit.t23d_forward(sd, x, t, cc, 2), z, c, osamp.SpacedTables('ddim25'),
+                               float(g['eta']), float(g['scale']), None, noises)
+    assert rel_l2(y, g['final']) < 1e-4

@@ -63,3 +63,22 @@ def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
     e0, e24, e = rel_l2(tr[0].cpu(), g['step0']), rel_l2(tr[24].cpu(), g['step24']), rel_l2(y.cpu(), g['final'])
     print('config1 step0', e0, 'step24', e24, 'final', e)
     assert e0 < 2e-3 and e < 5e-2, (e0, e24, e)
+
+
+@pytest.mark.parametrize("spec", ['ddim50', 'ddim25'])
+def test_ddim_cfg_vs_reference_golden(hip_lib, spec):
+    from ln3diff_amd.guided_diffusion import gaussian_diffusion as gd
+    from ln3diff_amd.guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    from ln3diff_amd.synth import synth_input
+    g = golden(f'ddim_tiny_{spec}')
+    m = _tiny()
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, spec), betas=gd.get_named_beta_schedule('linear', 1000))
+    z = synth_input('z', (2, 12, 32, 32), 41).cuda()
+    c = synth_input('c', (2, 77, 768), 41).cuda()
+    torch.manual_seed(int(g['noise_seed']))
+    noises = [torch.randn(2, 12, 32, 32) for _ in range(diff.num_timesteps)]
+    y = diff.ddim_sample_loop(m, (2, 12, 32, 32), cond={'c_crossattn': c}, noise=z, clip_denoised=False, eta=float(g['eta']),
+                              unconditional_guidance_scale=float(g['scale']), step_noise=lambda k: noises[k])
+    e = rel_l2(y.cpu(), g['final'])
+    print('ddim', spec, e)
+    assert e < 5e-2, e
