@@ -60,6 +60,8 @@ typedef struct {
    *   which w writes out{w}: layout [B, heads, tok_pad, head_dim] if !(transpose_mask>>w & 1)
    *   else [B, heads, head_dim, tok_pad] with tokens key-permuted inside 16-groups (V^T for ln3d_attention_bf16). */
   int tokens; int tok_pad; int heads; int head_dim; int transpose_mask;
+  int head_dim_pad;   /* HEADS: destination head size (>= head_dim; 0 = head_dim).  DiT-XL/2 (head_dim 72) writes into
+                         128-wide zero-initialised heads so that ln3d_attention_bf16 (Dh 64/128) serves it */
 } ln3d_gemm_args;
 
 int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);

@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("out0", vp), ("out1", vp), ("out2", vp), ("ldo", i64),
                 ("gate", vp), ("gate_rows", i32), ("gate_ld", i64),
                 ("tokens", i32), ("tok_pad", i32), ("heads", i32), ("head_dim", i32),
-                ("transpose_mask", i32)]
+                ("transpose_mask", i32), ("head_dim_pad", i32)]
 
 
 class AttnArgs(C.Structure):

@@ -32,7 +32,7 @@ struct GemmP {
   int M, N, K;
   void* out0; void* out1; void* out2;
   const float* gate; int gate_rows; int64_t gate_ld;
-  int tokens, tok_pad, heads, head_dim, transpose_mask;
+  int tokens, tok_pad, heads, head_dim, transpose_mask, head_dim_pad;
 };
 
 template <int EPI>
@@ -78,12 +78,12 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
     const int64_t bh = (int64_t)b * p.heads + h;
     if (!((p.transpose_mask >> which) & 1)) {
       uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
-      *reinterpret_cast<uint2*>(dst + (bh * p.tok_pad + t) * p.head_dim + d) = o;
+      *reinterpret_cast<uint2*>(dst + (bh * p.tok_pad + t) * p.head_dim_pad + d) = o;
     } else {
       // V^T: tokens of every 16-group stored in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of t swapped) - the
       // order in which the attention kernel's S^T accumulator hands P to the PV MFMA (csrc/attention.hip)
       const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-      bf16_t* q = dst + (bh * p.head_dim + d) * p.tok_pad + tp;
+      bf16_t* q = dst + (bh * p.head_dim_pad + d) * p.tok_pad + tp;
       q[0] = f2bf(v0); q[p.tok_pad] = f2bf(v1); q[2 * (int64_t)p.tok_pad] = f2bf(v2); q[3 * (int64_t)p.tok_pad] = f2bf(v3);
     }
   }
@@ -419,6 +419,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.gate = a->gate; p.gate_rows = a->gate_rows > 0 ? a->gate_rows : 1; p.gate_ld = a->gate_ld;
   p.tokens = a->tokens; p.tok_pad = a->tok_pad; p.heads = a->heads; p.head_dim = a->head_dim;
   p.transpose_mask = a->transpose_mask;
+  p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
   hipStream_t s = (hipStream_t)stream;
   // tile selection: the 128x384 LDS-DMA kernel when the problem fills its tiles, the 128x128 kernel otherwise
   // (small M such as the per-sample adaLN / timestep GEMMs, narrow N such as the conv decoder's 32/64 channels)

@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .dit_models_xformers import DiTBlock, Workspace, bf16, f32, get_2d_sincos_pos_embed, self_attention_hip
+from .dit_models_xformers import (DiTBlock, Workspace, bf16, f32, get_2d_sincos_pos_embed, self_attention_hip,
+                                  pad_head_columns)
 
 
 class DiTBlock2(DiTBlock):
@@ -42,7 +43,7 @@ class DiT2(nn.Module):
         for b in self.blocks:
             q = {'ada_w': bf16(b.adaLN_modulation[1].weight, device), 'ada_b': f32(b.adaLN_modulation[1].bias, device),
                  'qkv_w': bf16(b.attn.qkv.weight, device), 'qkv_b': f32(b.attn.qkv.bias, device),
-                 'proj_w': bf16(b.attn.proj.weight, device), 'proj_b': f32(b.attn.proj.bias, device),
+                 'proj_w': bf16(pad_head_columns(b.attn.proj.weight.detach(), self.num_heads, self.embed_dim // self.num_heads), device), 'proj_b': f32(b.attn.proj.bias, device),
                  'fc1_w': bf16(b.mlp.mlp[0].weight, device), 'fc1_b': f32(b.mlp.mlp[1].bias, device),
                  'fc2_w': bf16(b.mlp.mlp[2].weight, device), 'fc2_b': f32(b.mlp.mlp[3].bias, device)}
             P['blocks'].append(q)

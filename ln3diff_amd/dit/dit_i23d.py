@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import ops
 from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
-                                  self_attention_hip)
+                                  self_attention_hip, pad_head_columns)
 from .dit_trilatent import DiT, DiT_TriLatent
 
 
@@ -60,7 +60,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             q['n1'], q['n2'] = f32(b.norm1.weight, device), f32(b.norm2.weight, device)
             q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
             q['qn'], q['kn'] = f32(b.attn.q_norm.weight, device), f32(b.attn.k_norm.weight, device)
-            q['proj_w'], q['proj_b'] = bf16(b.attn.proj.weight, device), f32(b.attn.proj.bias, device)
+            q['proj_w'], q['proj_b'] = bf16(pad_head_columns(b.attn.proj.weight.detach(), self.num_heads, self.embed_dim // self.num_heads), device), f32(b.attn.proj.bias, device)
             q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
             q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
             q['cqn'], q['ckn'] = f32(b.cross_attn.q_norm.weight, device), f32(b.cross_attn.k_norm.weight, device)

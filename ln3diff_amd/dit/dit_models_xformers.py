@@ -200,23 +200,40 @@ class Workspace:
         return t
 
 
+def attn_head_pad(Dh):
+    """Head size the attention kernel runs at: 64 and 128 natively, anything else (DiT-XL/2: 72) zero-padded to 128."""
+    return Dh if Dh in (64, 128) else 128
+
+
+def pad_head_columns(w, H, Dh):
+    """proj weight [D_out, H*Dh] -> [D_out, H*Dh_pad] with zero columns, matching the padded attention output."""
+    Dp = attn_head_pad(Dh)
+    if Dp == Dh:
+        return w
+    out = w.new_zeros(w.shape[0], H, Dp)
+    out[:, :, :Dh] = w.reshape(w.shape[0], H, Dh)
+    return out.reshape(w.shape[0], H * Dp)
+
+
 def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=None, nq=None):
-    """h [B*N, D] bf16 -> attention output bf16 [B*nq, D] (nq <= N query rows kept)."""
+    """h [B*N, D] bf16 -> attention output bf16 [B*nq, H*Dh_pad] (nq <= N query rows kept).  For head sizes other than
+    64/128 the QKV epilogue writes into 128-wide zero-initialised heads (exact: the extra dims contribute 0 to q.k and
+    produce 0 output columns, which meet zero columns of the padded proj weight)."""
     Dh = D // H
-    if Dh not in (64, 128):
-        raise NotImplementedError(f"head_dim {Dh} (DiT-XL/2 self-attention) is not built yet")
+    Dp = attn_head_pad(Dh)
+    assert qn is None or Dp == Dh
     nq = N if nq is None else nq
     npad = (N + 63) // 64 * 64
-    q = ws.get(tag + 'q', (B, H, npad, Dh), torch.bfloat16, zero=True)
-    k = ws.get(tag + 'k', (B, H, npad, Dh), torch.bfloat16, zero=True)
-    vt = ws.get(tag + 'vt', (B, H, Dh, npad), torch.bfloat16, zero=True)
-    o = ws.get(tag + 'o', (B * nq, D), torch.bfloat16)
+    q = ws.get(tag + 'q', (B, H, npad, Dp), torch.bfloat16, zero=True)
+    k = ws.get(tag + 'k', (B, H, npad, Dp), torch.bfloat16, zero=True)
+    vt = ws.get(tag + 'vt', (B, H, Dp, npad), torch.bfloat16, zero=True)
+    o = ws.get(tag + 'o', (B * nq, H * Dp), torch.bfloat16)
     ops.gemm(h_bf16, qkv_w, qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
-             transpose_mask=0b100)
+             transpose_mask=0b100, head_dim_pad=Dp)
     if qn is not None:
         ops.rmsnorm_heads(q, qn, B * H * npad, Dh)
         ops.rmsnorm_heads(k, kn, B * H * npad, Dh)
-    ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dh)
+    ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dp, scale=Dh ** -0.5)
     return o
 
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import ops
 from .dit_models_xformers import (CaptionEmbedder, DiTBlock, FinalLayer, PatchEmbed, T2IFinalLayer,  # noqa: F401
                                   TextCondDiTBlock, TimestepEmbedder, Workspace, bf16, f32,
-                                  get_2d_sincos_pos_embed, self_attention_hip)
+                                  get_2d_sincos_pos_embed, self_attention_hip, pad_head_columns)
 
 
 class DiT(nn.Module):
@@ -139,7 +139,7 @@ class DiT_TriLatent(DiT):
         for b in self.blocks:
             q = {}
             q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
-            q['proj_w'], q['proj_b'] = bf16(b.attn.proj.weight, device), f32(b.attn.proj.bias, device)
+            q['proj_w'], q['proj_b'] = bf16(pad_head_columns(b.attn.proj.weight.detach(), self.num_heads, self.embed_dim // self.num_heads), device), f32(b.attn.proj.bias, device)
             q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
             q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
             q['co_w'], q['co_b'] = bf16(b.cross_attn.to_out[0].weight, device), f32(b.cross_attn.to_out[0].bias, device)

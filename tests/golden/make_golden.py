@@ -98,7 +98,7 @@ def sec_t23d():
     check('tiny D128 L2 forward', y_or, y_ref)
     save('t23d_tiny', y=y_ref, t=t, manifest=manifest_json(shapes))
 
-    for arch, B in (('DiT-B/2', 1), ('DiT-L/2', 2)):
+    for arch, B in (('DiT-B/2', 1), ('DiT-L/2', 2), ('DiT-XL/2', 1)):
         hidden, depth, heads = odit.DIT_CONFIGS[arch]
         t0 = time.time()
         m = build_t23d(hidden, depth, heads)

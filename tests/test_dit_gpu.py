@@ -37,7 +37,8 @@ def test_t23d_tiny_vs_golden_and_oracle(hip_lib):
     assert e < TOL, e
 
 
-@pytest.mark.parametrize("arch,B,tag", [('DiT-B/2', 1, 't23d_dit_b2'), ('DiT-L/2', 2, 't23d_dit_l2')])
+@pytest.mark.parametrize("arch,B,tag", [('DiT-B/2', 1, 't23d_dit_b2'), ('DiT-L/2', 2, 't23d_dit_l2'),
+                                        ('DiT-XL/2', 1, 't23d_dit_xl2')])
 def test_t23d_full_vs_golden(hip_lib, arch, B, tag):
     from ln3diff_amd.dit.dit_trilatent import DiT_models
     from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
