@@ -157,6 +157,11 @@ int ln3d_flow_euler_step(float* x2, const float* v2, float dt, float cfg_scale, 
 int ln3d_add_table_rows(const float* t0, const float* tables, float* out, int layers, int B, int64_t W, void* stream);
 /* forward_with_cfg (dit/dit_i23d.py:155-168): v[2B] = [cond ; uncond] -> both halves = uncond + s*(cond-uncond) */
 int ln3d_cfg_combine_dup(float* v2, float cfg_scale, int64_t n_half, void* stream);
+/* Runge-Kutta stage combination out = y + sum_j cs[j]*ks[j] (y may be NULL; ks/cs are HOST arrays of <= 7 device pointers /
+ * coefficients) and acc = sum((err/(atol + rtol*max(|y0|,|y1|)))^2) - the adaptive Dormand-Prince solver behind
+ * transport's sampling_method='dopri5' (transport/integrators.py:112-119 -> torchdiffeq, third-party: parity unpinned) */
+int ln3d_lincomb(const float* y, const float* const* ks, const float* cs, int nterms, float* out, int64_t n, void* stream);
+int ln3d_err_ratio_sq(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc, int64_t n, void* stream);
 /* y = a*x + b*y (axpby, f32) - Heun / generic combinations */
 int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 
@@ -199,6 +204,15 @@ int ln3d_render_triplane(const ln3d_render_args* a, void* stream);
 int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P,
                       const float* dec_w0, const float* dec_b0, const float* dec_w1, const float* dec_b1,
                       float box_warp, float* sigma, float* rgb, void* stream);
+
+/* ---------------------------------------------------------------- iso-surface of the sigma grid (mesh export)
+ * Replaces mcubes.marching_cubes(sigma[G,G,G], thr) at nsr/train_util_diffusion.py:221 (PyMCubes, third-party, absent:
+ * parity unpinned) with marching tetrahedra.  Pass 1: triangles per cell -> counts[(G-1)^3] (cell = (x*(G-1)+y)*(G-1)+z);
+ * caller takes the inclusive prefix sum; pass 2 writes for triangle k its 3 vertices (grid coordinates) to
+ * tri_pos[k*9..] and the ids of the grid edges they lie on to tri_key[k*3..] (for welding).                          */
+int ln3d_mesh_count(const float* sigma, int G, float thr, int32_t* counts, void* stream);
+int ln3d_mesh_emit(const float* sigma, int G, float thr, const int64_t* offsets_inclusive, float* tri_pos, int64_t* tri_key,
+                   void* stream);
 
 /* ---------------------------------------------------------------- conv decoder pieces (channel-last f32/bf16)
  * GroupNorm(32, eps 1e-6, affine) + optional swish over x f32 [N, HW, C] -> bf16 (ldm model.py:45-51)        */

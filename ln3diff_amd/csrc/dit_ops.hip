@@ -383,6 +383,45 @@ extern "C" int ln3d_cfg_combine_dup(float* v2, float cfg_scale, int64_t n_half, 
   return ln3d_check_launch();
 }
 
+// Runge-Kutta helpers for the adaptive ODE solver (transport 'dopri5'): out = y + sum_j c[j] * k[j] (up to 7 stages), and
+// the RMS-norm error ratio accumulator sum((err / (atol + rtol * max(|y0|, |y1|)))^2).
+struct LinCombP { const float* k[7]; float c[7]; int n; };
+__global__ void lincomb_kernel(const float* y, LinCombP p, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = y ? y[i] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+    if (j < p.n) acc += p.c[j] * p.k[j][i];
+  out[i] = acc;
+}
+extern "C" int ln3d_lincomb(const float* y, const float* const* ks, const float* cs, int nterms, float* out, int64_t n, void* stream) {
+  if (!out || nterms < 0 || nterms > 7 || n <= 0) return LN3D_ERR_BAD_ARG;
+  LinCombP p{};
+  p.n = nterms;
+  for (int j = 0; j < nterms; ++j) { p.k[j] = ks[j]; p.c[j] = cs[j]; }
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, p, out, n);
+  return ln3d_check_launch();
+}
+__global__ void err_ratio_sq_kernel(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float v = 0.f;
+  if (i < n) {
+    const float tol = atol + rtol * fmaxf(fabsf(y0[i]), y1 ? fabsf(y1[i]) : 0.f);
+    const float r = err[i] / tol;
+    v = r * r;
+  }
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, v);
+}
+extern "C" int ln3d_err_ratio_sq(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc,
+                                 int64_t n, void* stream) {
+  if (!err || !y0 || !acc || n <= 0) return LN3D_ERR_BAD_ARG;
+  if (hipMemsetAsync(acc, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return LN3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(err_ratio_sq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, err, y0, y1, atol, rtol, acc, n);
+  return ln3d_check_launch();
+}
+
 // ------------------------------------------------------------------ misc
 extern "C" const char* ln3d_strerror(int code) {
   switch (code) {

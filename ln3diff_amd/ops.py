@@ -172,3 +172,23 @@ def ddim_step(x, eps_u, eps_c, noise, cfg_scale, a, b, sqrt_ab_prev, coef_eps, s
     L.check(L.lib().ln3d_ddim_step(_p(x), _p(eps_u), _p(eps_c), _p(noise), C.c_float(cfg_scale), C.c_float(a), C.c_float(b),
                                    C.c_float(sqrt_ab_prev), C.c_float(coef_eps), C.c_float(sigma), int(clip),
                                    C.c_int64(x.numel()), _stream()), "ddim_step")
+
+
+def mesh_count(sigma, G, thr, counts):
+    L.check(L.lib().ln3d_mesh_count(_p(sigma), G, C.c_float(thr), _p(counts), _stream()), "mesh_count")
+
+
+def mesh_emit(sigma, G, thr, offsets, tri_pos, tri_key):
+    L.check(L.lib().ln3d_mesh_emit(_p(sigma), G, C.c_float(thr), _p(offsets), _p(tri_pos), _p(tri_key), _stream()), "mesh_emit")
+
+
+def lincomb(y, ks, cs, out):
+    n = len(ks)
+    arr_k = (C.c_void_p * n)(*[k.data_ptr() for k in ks])
+    arr_c = (C.c_float * n)(*[float(c) for c in cs])
+    L.check(L.lib().ln3d_lincomb(_p(y), arr_k, arr_c, n, _p(out), C.c_int64(out.numel()), _stream()), "lincomb")
+
+
+def err_ratio_sq(err, y0, y1, atol, rtol, acc):
+    L.check(L.lib().ln3d_err_ratio_sq(_p(err), _p(y0), _p(y1), C.c_float(atol), C.c_float(rtol), _p(acc),
+                                      C.c_int64(err.numel()), _stream()), "err_ratio_sq")

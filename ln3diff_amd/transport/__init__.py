@@ -4,8 +4,8 @@ Surface of the reference's transport package for the sampling path: create_trans
 Sampler(transport).sample_ode(sampling_method, num_steps, atol, rtol, reverse)(x, model_fn, **kw) -> [T, ...]
 (transport/__init__.py:3-71, transport/transport.py:374-420, transport/integrators.py:78-120).
 Linear path + velocity prediction: dx/dt = model(x, t), t from 0 (noise) to 1 (data).  Fixed-grid
-'euler' and 'heun' are built; the reference's default adaptive 'dopri5' lives in torchdiffeq (absent,
-parity unpinned - SURVEY.md §8c) and is a listed next item.
+'euler' and 'heun' plus an own adaptive Dormand-Prince 5(4) ('dopri5', the reference's default, which lives in the absent
+third-party torchdiffeq: parity unpinned - SURVEY.md §8c; validated by convergence to the fixed-step solution).
 """
 import torch
 
@@ -31,9 +31,10 @@ class Sampler:
         self.transport = transport
 
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False, cfg=False):
+        if sampling_method == "dopri5":
+            return _dopri5_sampler(num_steps, atol, rtol)
         if sampling_method not in ("euler", "heun"):
-            raise NotImplementedError(f"ODE method '{sampling_method}': only fixed-grid euler/heun are built "
-                                      "(adaptive dopri5 is a third-party solver absent from the reference tree)")
+            raise NotImplementedError(f"ODE method '{sampling_method}'")
         assert not reverse
         ts = torch.linspace(0.0, 1.0, num_steps)
 
@@ -61,3 +62,83 @@ class Sampler:
                     traj.append(x.clone())
             return torch.stack(traj, 0) if return_trajectory else x[None]
         return sample
+
+
+# ----------------------------------------------------------------------------- adaptive Dormand-Prince 5(4)
+_DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_A = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9],
+         [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+         [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+         [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
+_DP_B5 = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0]
+_DP_B4 = [5179 / 57600, 0.0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 1 / 40]
+_DP_E = [b5 - b4 for b5, b4 in zip(_DP_B5, _DP_B4)]
+
+
+def _dopri5_sampler(num_steps, atol, rtol, safety=0.9, ifactor=10.0, dfactor=0.2, max_steps=1000):
+    """Own Dormand-Prince 5(4) with FSAL, RMS error norm over the whole state, the usual 0.9*err^(-1/5) controller
+    (factor clamped to [0.2, 10]) and Hairer's initial-step heuristic.  Steps are clipped to the requested output
+    times t = linspace(0, 1, num_steps) (so no dense-output interpolation is needed and the model is never evaluated
+    outside [0, 1]); the trajectory at those times is returned like the reference's odeint call."""
+    ts = [float(v) for v in torch.linspace(0.0, 1.0, num_steps)]
+
+    @torch.no_grad()
+    def sample(x, model_fn, return_trajectory=True, **model_kwargs):
+        dev = x.device
+        y = x.clone().float().contiguous()
+        n = y.numel()
+        t_dev = torch.empty(y.shape[0], device=dev, dtype=torch.float32)
+        acc = torch.zeros(1, device=dev)
+
+        def f(t, yy):
+            t_dev.fill_(t)
+            return model_fn(yy, t_dev, **model_kwargs).contiguous()
+
+        def rms(err, y0, y1):
+            ops.err_ratio_sq(err, y0, y1, atol, rtol, acc)
+            return (float(acc.item()) / n) ** 0.5                       # host sync: the step-size decision is host-side
+
+        k = [None] * 7
+        k[0] = f(0.0, y)
+        # initial step (Hairer, Norsett, Wanner II.4), order 5
+        zero = torch.zeros_like(y)
+        d0, d1 = rms(y, y, None), rms(k[0], y, None)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        y1 = torch.empty_like(y)
+        ops.lincomb(y, [k[0]], [h0], y1)
+        f1 = f(h0, y1)
+        df = torch.empty_like(y)
+        ops.lincomb(None, [f1, k[0]], [1.0, -1.0], df)
+        d2 = rms(df, y, None) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+        h = min(100 * h0, h1)
+        traj = [y.clone()] if return_trajectory else None
+        t, nfe, steps = 0.0, 2, 0
+        ynew, err, ystage = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        for t_out in ts[1:]:
+            while t < t_out - 1e-12:
+                if steps >= max_steps:
+                    raise RuntimeError("dopri5: max_steps exceeded")
+                hh = min(h, t_out - t)
+                for s in range(1, 7):
+                    ops.lincomb(y, k[:s], [hh * a for a in _DP_A[s]], ystage)
+                    if s < 6:
+                        k[s] = f(t + _DP_C[s] * hh, ystage)
+                    else:
+                        ynew.copy_(ystage)                              # stage 7 input == 5th-order solution (FSAL)
+                        k[6] = f(t + hh, ynew)
+                nfe += 6
+                ops.lincomb(None, k, [hh * e for e in _DP_E], err)
+                ratio = rms(err, y, ynew)
+                steps += 1
+                if ratio <= 1.0:
+                    t += hh
+                    y.copy_(ynew)
+                    k[0] = k[6]
+                fac = ifactor if ratio == 0 else min(ifactor, max(safety * ratio ** -0.2, 1.0 if ratio < 1 else dfactor))
+                h = hh * fac if ratio > 1.0 or hh == h else max(h, hh * fac)
+            if return_trajectory:
+                traj.append(y.clone())
+        sample.last_stats = {'nfe': nfe, 'steps': steps}
+        return torch.stack(traj, 0) if return_trajectory else y[None]
+    return sample

@@ -156,8 +156,10 @@ def main():
         with open(os.path.join(args.logdir, f"sample{lo}_view0.ppm"), "wb") as f:
             f.write(b"P6 %d %d 255\n" % (f0.shape[1], f0.shape[0]) + f0.tobytes())
         if args.export_mesh:
-            grid = dec.triplane_decode_grid(dec_out, args.mesh_grid)
-            np.save(os.path.join(args.logdir, f"sigma_grid_rank{rank}.npy"), grid["sigma"].cpu().numpy())
+            from ln3diff_amd.mesh import export_mesh           # sigma grid -> iso-surface (thr 10) -> coloured .obj
+            for i in range(latent.shape[0]):
+                export_mesh(dec, dec_out, os.path.join(args.logdir, f"sample{lo + i}.obj"), grid_size=args.mesh_grid,
+                            thr=10.0, sample_index=i)
         lat_all = parallel.all_gather_cat(latent)
         if rank == 0:
             np.save(os.path.join(args.logdir, "latents_all.npy"), lat_all.cpu().numpy())

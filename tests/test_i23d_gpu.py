@@ -63,3 +63,29 @@ def test_flow_matching_ode_vs_reference_golden(hip_lib, method, steps):
     e = rel_l2(y, g['final'])
     print('flow', method, steps, e)
     assert e < 5e-2, e
+
+
+def test_dopri5_converges_to_fixed_step_solution(hip_lib):
+    """Adaptive Dormand-Prince (parity unpinned: torchdiffeq is absent) must agree with a fine fixed-step Heun solution of
+    the same ODE, and tighter tolerances must get closer."""
+    from ln3diff_amd.synth import synth_input
+    from ln3diff_amd.transport import Sampler, create_transport
+    m = _build(128, 2, 2)
+    load_synth(m, 0)
+    m = m.cuda()
+    z = synth_input('z', (2, 12, 32, 32), 42).cuda()
+    cond = {'crossattn': synth_input('ca', (2, 256, 2048), 42).cuda(), 'vector': synth_input('v', (2, 768), 42).cuda()}
+    ctx = {k: torch.cat([v, torch.zeros_like(v)], 0) for k, v in cond.items()}
+    cache = m.prepare_context(ctx)
+    S = Sampler(create_transport(snr_type='lognorm'))
+    zz = torch.cat([z, z])
+    ref = S.sample_ode(sampling_method='heun', num_steps=201)(zz, m.forward_with_cfg, return_trajectory=False,
+                                                              context_cache=cache, cfg_scale=4.0)[-1]
+    errs = []
+    for rtol in (1e-2, 1e-3, 1e-4):
+        fn = S.sample_ode(sampling_method='dopri5', num_steps=5, atol=1e-6, rtol=rtol)
+        y = fn(zz, m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)
+        assert y.shape[0] == 5
+        errs.append(rel_l2(y[-1].cpu(), ref.cpu()))
+        print('dopri5 rtol', rtol, 'rel-l2 vs heun-200', errs[-1], fn.last_stats)
+    assert errs[-1] < 5e-3 and errs[-1] <= errs[0] * 1.5
