@@ -33,6 +33,7 @@ struct GemmP {
   void* out0; void* out1; void* out2;
   const float* gate; int gate_rows; int64_t gate_ld;
   int tokens, tok_pad, heads, head_dim, transpose_mask, head_dim_pad;
+  int abl;   // bench-only ablation bits for the 256-wide kernel (LN3D_GEMM_ABL): 1 = skip the epilogue, 2 = 4 K-stages only
 };
 
 template <int EPI>
@@ -199,6 +200,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 }
 
 // =================================================================================================
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue of the LDS-DMA kernels.  A lane's accumulator quad is 4 consecutive features of ONE token and lanes 0-31 are 32
+// different tokens, so storing straight from the accumulators writes 16-byte pieces scattered over 32 output rows per
+// instruction (measured: ~1.5 TB/s, a third of a K = 1024 GEMM).  Instead every wave transposes its own sub-tile through a
+// private 8 KB fp32 LDS region (the ring is free after the main loop), 32 tokens x 64 features at a time, and comes back
+// with 16 consecutive lanes holding the 64 consecutive features of one token: each store instruction then writes four
+// complete 128-byte (bf16) / 256-byte (f32) row segments and the bias / gate / residual traffic is row-contiguous too.
+// 256-byte staging rows, 16-byte chunk c of row r stored at chunk c ^ (r & 15): conflict-free ds_write_b128 (8-lane
+// groups = 8 rows) and ds_read_b128 (16-lane groups) without padding.  DS operations of one wave execute in order, so
+// no barrier is needed beyond the caller's one that retires the ring.
+template <int EPI, int NI, int NJ>
+__device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
+  static_assert(NI % 2 == 0, "feature blocks are staged in pairs");
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int rrow = lane >> 4, rc = lane & 15;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int ih = 0; ih < NI / 2; ++ih) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = ii * 8 + 2 * g + hi;
+          *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
+              make_float4(acc[2 * ih + ii][j][4 * g + 0], acc[2 * ih + ii][j][4 * g + 1], acc[2 * ih + ii][j][4 * g + 2],
+                          acc[2 * ih + ii][j][4 * g + 3]);
+        }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = 4 * it + rrow;
+        const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+        const int tok = tw0 + j * 32 + row, fb = fw0 + ih * 64 + 4 * rc;
+        if (tok < p.M && fb < p.N) epilogue4<EPI>(p, tok, fb, v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+}
+
 // Large-tile variant: 128(features) x 384(tokens) x 32(K) stages, 8 waves (2 x 4), wave tile 64f x 96t
 // (2 x 3 MFMA 32x32x16 tiles, 96 accumulator registers), 4-deep LDS ring filled by LDS-DMA
 // (global_load_lds_dwordx4: HBM/L2 -> LDS without touching VGPRs), counted vmcnt so that the loads of the
@@ -365,20 +405,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_large_kernel(GemmP p) {
     if (s + 1 < ns) L_ITER(s + 1, fa1, fb1, fa0, fb0);
   }
 
+  bool direct = false;                                // V^T emission wants token-contiguous stores: direct path
+  if constexpr (EPI == LN3D_EPI_HEADS) direct = (p.transpose_mask != 0) && (f0 + L_BF > 2 * p.heads * p.head_dim);
+  if (direct) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int tok = t0 + wt * 96 + j * 32 + l31;
-    if (tok >= p.M) continue;
+    for (int j = 0; j < 3; ++j) {
+      const int tok = t0 + wt * 96 + j * 32 + l31;
+      if (tok >= p.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fb = f0 + wf * 64 + i * 32 + 8 * g + 4 * hi;
-        if (fb < p.N)
-          epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          const int fb = f0 + wf * 64 + i * 32 + 8 * g + 4 * hi;
+          if (fb < p.N)
+            epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
       }
     }
+    return;
   }
+  __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
+  staged_epilogue<EPI, 2, 3>(p, acc, smem + wid * 8192, f0 + wf * 64, t0 + wt * 96, lane);
 }
 
 template <int EPI, int ABL = 0>
@@ -392,6 +439,357 @@ static int launch_large(const GemmP& p, hipStream_t s) {
   const int nft = (p.N + L_BF - 1) / L_BF, ntt = (p.M + L_BT - 1) / L_BT;
   hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, ABL>), dim3(nft * ntt), dim3(512), L_LDS, s, p);
   return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Generic LDS-DMA ring kernel: NW waves as (NW/WGT) x WGT, wave tile 32*NI features x 32*NJ tokens, K stages of 32,
+// 4-deep ring, same swizzle / fragment layout as the 128x384 kernel above.  What the configurations trade is the
+// byte/flop ratio of the L2 -> LDS fill (the measured limiter, ~12 TB/s chip-wide) against rounds of 256 tiles:
+//   NW 8, 2x4 waves, 4x2 blocks : 256f x 256t, 128 flop/B, 2 waves/SIMD  (N = 4096: 768 tiles = 3 rounds)
+//   NW 4, 2x2 waves, 4x4 / 4x3  : 256f x 256t / 192t with one wave per SIMD and 256 / 192 accumulator registers
+// The pipeline runs at K-substep (16) granularity with two fragment register sets: substep 0 of a stage multiplies while
+// substep 1 is read, the stage barrier sits between them, and the reads of stage s+1 and the DMA issues of stage s+4 are
+// slotted one per MFMA behind it (sched_barrier pins the interleave).
+template <int EPI, int NW, int WGT, int NI, int NJ>
+__global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring_kernel(GemmP p) {
+  constexpr int WGF = NW / WGT, BF = 32 * NI * WGF, BT = 32 * NJ * WGT;
+  constexpr int WB = BF * 64, STAGEB = (BF + BT) * 64, NPW = (BF + BT) / 16 / NW;
+  static_assert((BF + BT) / 16 % NW == 0, "DMA instructions must divide evenly over the waves");
+  constexpr int NM = NI * NJ, NR = NI + NJ, NFREE = NM - NR;
+  static_assert(NFREE >= 0, "one fragment read per MFMA slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wid / WGT, wt = wid % WGT;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware tile map: an XCD owns ntt/8 token panels and walks the feature tiles in groups of 4, so the <= 32 tiles
+  // that run together on it share 4 W panels and its own X panels and X is fetched once per XCD.
+  const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
+  const int ntiles = nft * ntt;
+  int ft, tt;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    if ((ntt & 7) == 0 && (nft & 3) == 0) {
+      const int rows = ntt >> 3;
+      const int g = slot / (rows * 4), rem = slot - g * rows * 4;
+      ft = g * 4 + (rem & 3);
+      tt = xcd * rows + (rem >> 2);
+    } else {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+      ft = tile % nft; tt = tile / nft;
+    }
+  }
+  const int f0 = ft * BF, t0 = tt * BT;
+
+  // DMA instruction idx (16 rows x 64 B each; W rows first, then X rows) -> LDS bytes [idx*1024, +1024) of the stage;
+  // wave w issues idx = w*NPW .. w*NPW+NPW-1
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const bf16_t* src[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int idx = wid * NPW + q;
+    if (idx < BF / 16) {
+      int r = f0 + 16 * idx + lrow; r = r < p.N ? r : p.N - 1;
+      src[q] = p.W + (int64_t)r * p.ldw + lchunk * 8;
+    } else {
+      int r = t0 + 16 * (idx - BF / 16) + lrow; r = r < p.M ? r : p.M - 1;
+      src[q] = p.X + (int64_t)r * p.ldx + lchunk * 8;
+    }
+  }
+  const int dst0 = wid * NPW * 1024;
+#define X_ISSUE1(s, q)                                                                                       \
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(src[q] + (s) * L_BK),                                        \
+      (lds_void_t*)(smem + ((s) & 3) * STAGEB + dst0 + (q) * 1024), 16, 0, 0)
+
+  const int key = (l31 >> 2) & 3;
+  const int a_off = (wf * 32 * NI + l31) * 64 + ((hi ^ key) << 4);
+  const int b_off = WB + (wt * 32 * NJ + l31) * 64 + ((hi ^ key) << 4);
+#define X_RDA(s, ks, i) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 3) * STAGEB + ((a_off + (i) * 2048) ^ ((ks) << 5))))
+#define X_RDB(s, ks, j) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 3) * STAGEB + ((b_off + (j) * 2048) ^ ((ks) << 5))))
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
+  const int ns = (p.abl & 2) ? 4 : p.K / L_BK;
+
+  // prologue: up to 4 stages in flight, wait for the first
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) X_ISSUE1(0, q);
+  if (ns > 1) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) X_ISSUE1(1, q); }
+  if (ns > 2) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) X_ISSUE1(2, q); }
+  if (ns > 3) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) X_ISSUE1(3, q); }
+  if (ns > 3) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPW) : "memory"); }
+  else if (ns > 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory"); }
+  else if (ns > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); }
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a0[i] = X_RDA(0, 0, i);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b0[j] = X_RDB(0, 0, j);
+
+  // MFMA n of a substep is block (n / NJ, n % NJ); behind MFMA n one or more memory instructions are slotted in
+#define X_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
+#define X_PIN() __builtin_amdgcn_sched_barrier(0)
+  // one stage; FILL / MORE / WAITN are literals so the body is branch-free
+#define X_STAGE(s, FILL, MORE, WAITN)                                                                     \
+  {                                                                                                       \
+    /* substep 0: multiply set 0, read substep 1 of this stage into set 1 */                              \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
+      X_MMA(a0, b0, n);                                                                                   \
+      if (n < NI) a1[n] = X_RDA(s, 1, n);                                                                 \
+      else if (n < NR) b1[n - NI] = X_RDB(s, 1, n - NI);                                                  \
+      X_PIN();                                                                                            \
+    }                                                                                                     \
+    if (MORE) {                                                                                           \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                                        \
+      __builtin_amdgcn_s_waitcnt(0xC07F); /* set-1 fragments in registers; this wave is done with slot s */ \
+      __builtin_amdgcn_s_barrier();                                                                       \
+    }                                                                                                     \
+    /* substep 1: multiply set 1; behind it substep 0 of stage s+1 and the DMAs of stage s+4 (slot just released) */ \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
+      X_MMA(a1, b1, n);                                                                                   \
+      if (n < NI) { if (MORE) a0[n] = X_RDA((s) + 1, 0, n); }                                             \
+      else if (n < NR) { if (MORE) b0[n - NI] = X_RDB((s) + 1, 0, n - NI); }                              \
+      if (FILL) {                                                                                         \
+        _Pragma("unroll") for (int d = 0; d < NPW; ++d)                                                   \
+            if ((NFREE > 0 ? NR + d * NFREE / NPW : NM - 1) == n) X_ISSUE1((s) + 4, d);                   \
+      }                                                                                                   \
+      X_PIN();                                                                                            \
+    }                                                                                                     \
+  }
+  int s = 0;
+  for (; s + 4 < ns; ++s) X_STAGE(s, true, true, 2 * NPW);
+  if (ns >= 4) { X_STAGE(s, false, true, 2 * NPW); ++s; }
+  if (ns >= 3) { X_STAGE(s, false, true, NPW); ++s; }
+  if (ns >= 2) { X_STAGE(s, false, true, 0); ++s; }
+  X_STAGE(s, false, false, 0);
+
+  if ((p.abl & 1) && acc[0][0][0] != 12345.f) return;
+  bool direct = false;                                // V^T emission wants token-contiguous stores: direct path
+  if constexpr (EPI == LN3D_EPI_HEADS) direct = (p.transpose_mask != 0) && (f0 + BF > 2 * p.heads * p.head_dim);
+  if (direct) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int tok = t0 + wt * 32 * NJ + j * 32 + l31;
+      if (tok >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fb = f0 + wf * 32 * NI + i * 32 + 8 * g + 4 * hi;
+          if (fb < p.N)
+            epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+      }
+    }
+    return;
+  }
+  __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
+  staged_epilogue<EPI, NI, NJ>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
+}
+
+template <int EPI, int NW, int WGT, int NI, int NJ>
+static int launch_ring(const GemmP& p, hipStream_t s) {
+  constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT, LDSB = 4 * (BF + BT) * 64;
+  static_assert(LDSB >= NW * 8192, "staging regions live in the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI, NW, WGT, NI, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    attr_set = true;
+  }
+  const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
+  hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI, NW, WGT, NI, NJ>), dim3(nft * ntt), dim3(NW * 64), LDSB, s, p);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Same tile family with K stages of 64: an LDS row is a full 128-byte cache line of the operand (a 64-byte row makes every
+// DMA request touch half a line, and the other half is requested again one stage later), two 64 KB slots.  Swizzle for
+// 128-byte rows: 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (the attention kernel's K layout).
+// Stage = 4 K-substeps; the fragment sets alternate per substep; the barrier sits before substep 3, behind which the
+// first fragments of stage s+1 are read and the DMAs of stage s+2 are issued into the slot that substep 2 finished reading.
+template <int EPI, int NW, int WGT, int NI, int NJ>
+__global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP p) {
+  constexpr int WGF = NW / WGT, BF = 32 * NI * WGF, BT = 32 * NJ * WGT;
+  constexpr int WB = BF * 128, STAGEB = (BF + BT) * 128, NPW = (BF + BT) / 8 / NW;
+  static_assert((BF + BT) / 8 % NW == 0, "DMA instructions must divide evenly over the waves");
+  constexpr int NM = NI * NJ, NR = NI + NJ;
+  static_assert(NM >= NR, "one fragment read per MFMA slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wid / WGT, wt = wid % WGT;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
+  const int ntiles = nft * ntt;
+  int ft, tt;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    if ((ntt & 7) == 0 && (nft & 3) == 0) {
+      const int rows = ntt >> 3;
+      const int g = slot / (rows * 4), rem = slot - g * rows * 4;
+      ft = g * 4 + (rem & 3);
+      tt = xcd * rows + (rem >> 2);
+    } else {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+      ft = tile % nft; tt = tile / nft;
+    }
+  }
+  const int f0 = ft * BF, t0 = tt * BT;
+
+  // DMA instruction idx = 8 rows x 128 B (W rows first, then X rows) -> LDS bytes [idx*1024, +1024) of the slot
+  const int r8 = lane >> 3;
+  const bf16_t* src[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int idx = wid * NPW + q;
+    const int rt = 8 * (idx < BF / 8 ? idx : idx - BF / 8) + r8;          // row inside its own tile
+    const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
+    if (idx < BF / 8) {
+      int r = f0 + rt; r = r < p.N ? r : p.N - 1;
+      src[q] = p.W + (int64_t)r * p.ldw + chunk * 8;
+    } else {
+      int r = t0 + rt; r = r < p.M ? r : p.M - 1;
+      src[q] = p.X + (int64_t)r * p.ldx + chunk * 8;
+    }
+  }
+  const int dst0 = wid * NPW * 1024;
+#define Y_ISSUE1(s, q)                                                                                       \
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(src[q] + (s) * 64),                                          \
+      (lds_void_t*)(smem + ((s) & 1) * STAGEB + dst0 + (q) * 1024), 16, 0, 0)
+
+  const int key = (l31 >> 1) & 7;
+  const int a_row = (wf * 32 * NI + l31) * 128;
+  const int b_row = WB + (wt * 32 * NJ + l31) * 128;
+#define Y_RDA(s, ks, i) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + a_row + (i) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+#define Y_RDB(s, ks, j) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + b_row + (j) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
+  const int ns = (p.abl & 2) ? 2 : p.K / 64;
+
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) Y_ISSUE1(0, q);
+  if (ns > 1) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) Y_ISSUE1(1, q); }
+  if (ns > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); }
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a0[i] = Y_RDA(0, 0, i);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b0[j] = Y_RDB(0, 0, j);
+
+#define Y_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
+  // substep: multiply (CA, CB) while (s2, ks2) is read into (NA, NB)
+#define Y_PHASE(CA, CB, NA, NB, s2, ks2, RD)                                                              \
+  _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                        \
+    Y_MMA(CA, CB, n);                                                                                     \
+    if (RD) {                                                                                             \
+      if (n < NI) NA[n] = Y_RDA(s2, ks2, n);                                                              \
+      else if (n < NR) NB[n - NI] = Y_RDB(s2, ks2, n - NI);                                               \
+    }                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  }
+#define Y_STAGE(s, FILL, MORE)                                                                            \
+  {                                                                                                       \
+    Y_PHASE(a0, b0, a1, b1, s, 1, true);                                                                  \
+    Y_PHASE(a1, b1, a0, b0, s, 2, true);                                                                  \
+    Y_PHASE(a0, b0, a1, b1, s, 3, true);                                                                  \
+    if (MORE) {                                                                                           \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* stage s+1 (the only DMAs in flight) landed */  \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                 \
+      __builtin_amdgcn_s_barrier();                                                                       \
+    }                                                                                                     \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
+      Y_MMA(a1, b1, n);                                                                                   \
+      if (MORE) {                                                                                         \
+        if (n < NI) a0[n] = Y_RDA((s) + 1, 0, n);                                                         \
+        else if (n < NR) b0[n - NI] = Y_RDB((s) + 1, 0, n - NI);                                          \
+      }                                                                                                   \
+      if (FILL) {                                                                                         \
+        _Pragma("unroll") for (int d = 0; d < NPW; ++d)                                                   \
+            if (d * NM / NPW == n) Y_ISSUE1((s) + 2, d);                                                  \
+      }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+  }
+  int s = 0;
+  for (; s + 2 < ns; ++s) Y_STAGE(s, true, true);
+  if (ns >= 2) { Y_STAGE(s, false, true); ++s; }
+  Y_STAGE(s, false, false);
+
+  if ((p.abl & 1) && acc[0][0][0] != 12345.f) return;
+  bool direct = false;
+  if constexpr (EPI == LN3D_EPI_HEADS) direct = (p.transpose_mask != 0) && (f0 + BF > 2 * p.heads * p.head_dim);
+  if (direct) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int tok = t0 + wt * 32 * NJ + j * 32 + l31;
+      if (tok >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fb = f0 + wf * 32 * NI + i * 32 + 8 * g + 4 * hi;
+          if (fb < p.N)
+            epilogue4<EPI>(p, tok, fb, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+      }
+    }
+    return;
+  }
+  __builtin_amdgcn_s_barrier();
+  staged_epilogue<EPI, NI, NJ>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
+}
+
+template <int EPI, int NW, int WGT, int NI, int NJ>
+static int launch_ring64(const GemmP& p, hipStream_t s) {
+  constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT, LDSB = 2 * (BF + BT) * 128;
+  static_assert(LDSB >= NW * 8192, "staging regions live in the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    attr_set = true;
+  }
+  const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
+  hipLaunchKernelGGL((gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>), dim3(nft * ntt), dim3(NW * 64), LDSB, s, p);
+  return ln3d_check_launch();
+}
+
+// cfg: 3 / 4 = one wave per SIMD 256x192 / 256x256; 5 = 8 waves 256x256; 6 = 8 waves 128x384 (the hand-scheduled kernel's tile)
+template <int EPI>
+static int launch_xl_any(const GemmP& p, hipStream_t s, int cfg) {
+  switch (cfg) {
+    case 3: return launch_ring<EPI, 4, 2, 4, 3>(p, s);
+    case 4: return launch_ring<EPI, 4, 2, 4, 4>(p, s);
+    case 5: return launch_ring<EPI, 8, 4, 4, 2>(p, s);
+    case 7: return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
+    case 8: return launch_ring64<EPI, 8, 4, 2, 3>(p, s);
+    case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
+    case 10: return launch_ring64<EPI, 8, 4, 4, 3>(p, s);
+    default: return launch_ring<EPI, 8, 4, 2, 3>(p, s);
+  }
 }
 
 template <int EPI>
@@ -420,6 +818,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.tokens = a->tokens; p.tok_pad = a->tok_pad; p.heads = a->heads; p.head_dim = a->head_dim;
   p.transpose_mask = a->transpose_mask;
   p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
+  { const char* e = getenv("LN3D_GEMM_ABL"); p.abl = e ? atoi(e) : 0; }
   hipStream_t s = (hipStream_t)stream;
   // tile selection: the 128x384 LDS-DMA kernel when the problem fills its tiles, the 128x128 kernel otherwise
   // (small M such as the per-sample adaLN / timestep GEMMs, narrow N such as the conv decoder's 32/64 channels)
@@ -427,6 +826,26 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   bool large = a->M >= 1536 && a->N >= 128;
   if (force && force[0] == 's') large = false;
   if (force && force[0] == 'l') large = true;
+  int xl = 0;                                        // 0 = no, 3 / 4 = 256 x 192 / 256 x 256 tile
+  if (force && force[0] == 'x') xl = atoi(force + 1);
+  if (xl) {
+    switch (a->epilogue) {
+      case LN3D_EPI_F32: return launch_xl_any<LN3D_EPI_F32>(p, s, xl);
+      case LN3D_EPI_BF16: return launch_xl_any<LN3D_EPI_BF16>(p, s, xl);
+      case LN3D_EPI_GELU_ERF: return launch_xl_any<LN3D_EPI_GELU_ERF>(p, s, xl);
+      case LN3D_EPI_GELU_TANH: return launch_xl_any<LN3D_EPI_GELU_TANH>(p, s, xl);
+      case LN3D_EPI_SILU: return launch_xl_any<LN3D_EPI_SILU>(p, s, xl);
+      case LN3D_EPI_GATE_RES: return launch_xl_any<LN3D_EPI_GATE_RES>(p, s, xl);
+      case LN3D_EPI_F32_SILU:
+        if (!a->out1) return LN3D_ERR_BAD_ARG;
+        return launch_xl_any<LN3D_EPI_F32_SILU>(p, s, xl);
+      case LN3D_EPI_HEADS:
+        if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens)
+          return LN3D_ERR_BAD_ARG;
+        return launch_xl_any<LN3D_EPI_HEADS>(p, s, xl);
+      default: return LN3D_ERR_UNSUPPORTED;
+    }
+  }
   if (large) {
     switch (a->epilogue) {
       case LN3D_EPI_F32: return launch_large<LN3D_EPI_F32>(p, s);

@@ -11,7 +11,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "large", "small"])
+@pytest.fixture(scope="module", params=["auto", "large", "small", "x3", "x4", "x5", "x6", "x7", "x8", "x9", "x10"])
 def ops(hip_lib, request):
     """Every kernel test runs with the GEMM tile selection left to the library and forced to each tile config."""
     import os
@@ -20,7 +20,7 @@ def ops(hip_lib, request):
     if request.param == "auto":
         os.environ.pop("LN3D_GEMM_TILE", None)
     else:
-        os.environ["LN3D_GEMM_TILE"] = request.param[0]
+        os.environ["LN3D_GEMM_TILE"] = {"large": "l", "small": "s"}.get(request.param, request.param)
     yield o
     if old is None:
         os.environ.pop("LN3D_GEMM_TILE", None)

@@ -74,3 +74,13 @@ y = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
 mod = torch.randn(16, 6 * 1024, device=dev)
 us = timeit(lambda: ops.norm_modulate(x, y, M, 1024, shift=mod, scale=mod[:, 1024:], mod_rows=768, mod_ld=6144))
 print(f'LN+modulate 12288x1024            : {us:8.1f} us  {M * 1024 * 6 / us / 1e3:7.1f} GB/s')
+
+# yardstick only (not a product path): the vendor library GEMM at the same shapes
+if os.environ.get('KBENCH_VENDOR', '1') == '1':
+    for (nm, M_, N_, K_) in [('vendor fc1 shape', M, 4096, 1024), ('vendor fc2 shape', M, 1024, 4096),
+                             ('vendor qkv shape', M, 3072, 1024), ('vendor proj shape', M, 1024, 1024),
+                             ('vendor big square', 8192, 8192, 8192)]:
+        a = torch.randn(M_, K_, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N_, K_, device=dev) * 0.03).to(torch.bfloat16)
+        us = timeit(lambda: torch.matmul(a, w.t()))
+        print(f'{nm:34s} M{M_} N{N_} K{K_}: {us:8.1f} us  {2.0 * M_ * N_ * K_ / us / 1e6:7.1f} TF/s')
