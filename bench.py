@@ -68,7 +68,7 @@ def roofline_probe(dev, n_net, D, iters=20):
     # traffic: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch of this kernel at this shape, from the
     # separate rocprofv3 --pmc passes committed in profiles/r1_c_pmc.md (bench.py cannot run the profiler on itself)
     traffic = 268.9e6 if (M, N, K) == (12288, 4096, 1024) else None
-    return {"kernel": "gemm_bf16_large_kernel<GELU_ERF> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
+    return {"kernel": "gemm_bf16_ring64_kernel<GELU_ERF, 256x256> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
             "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": "profiles/r1_c_pmc.md (bytes per launch at the L2 fabric boundary)", "avg_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops}
