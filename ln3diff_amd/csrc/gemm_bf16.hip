@@ -210,15 +210,97 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 // 256-byte staging rows, 16-byte chunk c of row r stored at chunk c ^ (r & 15): conflict-free ds_write_b128 (8-lane
 // groups = 8 rows) and ds_read_b128 (16-lane groups) without padding.  DS operations of one wave execute in order, so
 // no barrier is needed beyond the caller's one that retires the ring.
+// Per-lane context of the staged epilogue: the lane keeps one feature quad fb and walks 32 consecutive tokens, so
+// everything that depends on fb (bias, head / dim split) or on the run's first token (sample index, gate rows, base
+// pointers) is computed once per run instead of once per store: the head-split epilogue spent more time in integer
+// divisions and 64-bit multiplies than in stores before this.
+template <int EPI>
+struct RunEpi {
+  float4 bias;
+  bool generic;            // a sample shorter than the run (or a transposed target): per-element path
+  // HEADS
+  bf16_t* hbase; int64_t hwrap; int hrows_left; int hstride;
+  // GATE_RES
+  float4 g0, g1; int grows_left;
+
+  __device__ __forceinline__ void init_feature(const GemmP& p, int fb, int& which, int& h, int& d) const {
+    const int dm = p.heads * p.head_dim;
+    which = fb / dm;
+    const int rem = fb - which * dm;
+    h = rem / p.head_dim; d = rem - h * p.head_dim;
+  }
+  __device__ __forceinline__ void init(const GemmP& p, int fb, int tb, int which, int h, int d) {
+    bias = p.bias ? *reinterpret_cast<const float4*>(p.bias + fb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    generic = false;
+    if constexpr (EPI == LN3D_EPI_HEADS) {
+      generic = p.tokens < 32 || ((p.transpose_mask >> which) & 1);
+      const int b0 = tb / p.tokens, t0 = tb - b0 * p.tokens;
+      bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+      hbase = dst + (((int64_t)b0 * p.heads + h) * p.tok_pad + t0) * p.head_dim_pad + d;
+      hwrap = ((int64_t)p.heads * p.tok_pad - p.tokens) * p.head_dim_pad;
+      hrows_left = p.tokens - t0;
+      hstride = p.head_dim_pad;
+    }
+    if constexpr (EPI == LN3D_EPI_GATE_RES) {
+      g0 = g1 = make_float4(1.f, 1.f, 1.f, 1.f);
+      grows_left = 1 << 30;
+      if (p.gate) {
+        generic = p.gate_rows < 32;
+        const int s0 = tb / p.gate_rows;
+        grows_left = p.gate_rows - (tb - s0 * p.gate_rows);
+        g0 = *reinterpret_cast<const float4*>(p.gate + (int64_t)s0 * p.gate_ld + fb);
+        if (grows_left < 32 && tb + grows_left < p.M) g1 = *reinterpret_cast<const float4*>(p.gate + (int64_t)(s0 + 1) * p.gate_ld + fb);
+      }
+    }
+  }
+  __device__ __forceinline__ void apply(const GemmP& p, int tb, int row, int fb, float4 v) const {
+    if constexpr (EPI == LN3D_EPI_HEADS) {
+      if (generic) { epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w); return; }
+      uint2 o; o.x = pack2bf(v.x + bias.x, v.y + bias.y); o.y = pack2bf(v.z + bias.z, v.w + bias.w);
+      *reinterpret_cast<uint2*>(hbase + (int64_t)row * hstride + (row >= hrows_left ? hwrap : 0)) = o;
+    } else if constexpr (EPI == LN3D_EPI_GATE_RES) {
+      if (generic) { epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w); return; }
+      const float4 g = row >= grows_left ? g1 : g0;
+      float4* xp = reinterpret_cast<float4*>((float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb);
+      float4 x = *xp;
+      x.x += (v.x + bias.x) * g.x; x.y += (v.y + bias.y) * g.y; x.z += (v.z + bias.z) * g.z; x.w += (v.w + bias.w) * g.w;
+      *xp = x;
+      if (p.out1) {
+        uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
+        *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)(tb + row) * p.ldo + fb) = o;
+      }
+    } else {
+      float v0 = v.x + bias.x, v1 = v.y + bias.y, v2 = v.z + bias.z, v3 = v.w + bias.w;
+      const int64_t off = (int64_t)(tb + row) * p.ldo + fb;
+      if constexpr (EPI == LN3D_EPI_F32 || EPI == LN3D_EPI_F32_SILU)
+        *reinterpret_cast<float4*>((float*)p.out0 + off) = make_float4(v0, v1, v2, v3);
+      if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+      if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+      if constexpr (EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_F32_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+      if constexpr (EPI != LN3D_EPI_F32) {
+        uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>((bf16_t*)(EPI == LN3D_EPI_F32_SILU ? p.out1 : p.out0) + off) = o;
+      }
+    }
+  }
+};
+
 template <int EPI, int NI, int NJ>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
   static_assert(NI % 2 == 0, "feature blocks are staged in pairs");
   const int l31 = lane & 31, hi = lane >> 5;
   const int rrow = lane >> 4, rc = lane & 15;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  for (int ih = 0; ih < NI / 2; ++ih) {
+    const int fb = fw0 + ih * 64 + 4 * rc;
+    const bool fok = fb < p.N;
+    RunEpi<EPI> re;
+    int which = 0, h = 0, d = 0;
+    if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
 #pragma unroll
-    for (int ih = 0; ih < NI / 2; ++ih) {
+    for (int j = 0; j < NJ; ++j) {
+      const int tb = __builtin_amdgcn_readfirstlane(tw0 + j * 32);
+      if (fok && tb < p.M) re.init(p, fb, tb, which, h, d);
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -232,8 +314,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
       for (int it = 0; it < 8; ++it) {
         const int row = 4 * it + rrow;
         const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
-        const int tok = tw0 + j * 32 + row, fb = fw0 + ih * 64 + 4 * rc;
-        if (tok < p.M && fb < p.N) epilogue4<EPI>(p, tok, fb, v.x, v.y, v.z, v.w);
+        if (tb + row < p.M && fok) re.apply(p, tb, row, fb, v);
       }
     }
   }

@@ -29,13 +29,14 @@ def gemm_case(name, M, N, K, epi, **kw):
     if epi == ops.EPI_GATE_RES:
         out = torch.randn(M, N, device=dev)
         gate = torch.randn(M // 768, 6 * N, device=dev)
-        f = lambda: ops.gemm(x, w, b, epi, out, gate=gate, gate_rows=768, gate_ld=6 * N)
+        cp = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if kw.get('copy') else None
+        f = lambda: ops.gemm(x, w, b, epi, out, cp, gate=gate, gate_rows=768, gate_ld=6 * N)
     elif epi == ops.EPI_HEADS:
         H = 16
         q = torch.zeros(M // 768, H, 768, 64, device=dev, dtype=torch.bfloat16)
         k = torch.zeros_like(q)
         vt = torch.zeros(M // 768, H, 64, 768, device=dev, dtype=torch.bfloat16)
-        f = lambda: ops.gemm(x, w, b, epi, q, k, vt, M=M, tokens=768, tok_pad=768, heads=H, head_dim=64, transpose_mask=0b100)
+        f = lambda: ops.gemm(x, w, b, epi, q, k, vt, M=M, tokens=768, tok_pad=768, heads=H, head_dim=64, transpose_mask=kw.get('tmask', 0b100))
     elif epi == ops.EPI_F32:
         out = torch.empty(M, N, device=dev)
         f = lambda: ops.gemm(x, w, b, epi, out)
@@ -48,7 +49,10 @@ def gemm_case(name, M, N, K, epi, **kw):
 
 M = 16 * 768
 gemm_case('qkv (HEADS, V^T)', M, 3072, 1024, ops.EPI_HEADS)
+gemm_case('qkv shape, plain BF16', M, 3072, 1024, ops.EPI_BF16)
+gemm_case('qkv (HEADS, no transpose)', M, 3072, 1024, ops.EPI_HEADS, tmask=0)
 gemm_case('proj (GATE_RES)', M, 1024, 1024, ops.EPI_GATE_RES)
+gemm_case('proj (GATE_RES + bf16 copy)', M, 1024, 1024, ops.EPI_GATE_RES, copy=True)
 gemm_case('cross to_q (BF16 plain)', M, 1024, 1024, ops.EPI_BF16)
 gemm_case('fc1 (GELU_ERF)', M, 4096, 1024, ops.EPI_GELU_ERF)
 gemm_case('fc1 shape, plain BF16', M, 4096, 1024, ops.EPI_BF16)
