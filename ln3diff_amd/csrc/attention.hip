@@ -35,6 +35,13 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // the order the S^T accumulator layout hands P to the second MFMA: the PV A-operand is one aligned 16-B read.
 // OCC = waves per SIMD the register allocation is bounded for: 4 (128 VGPRs, two workgroups per CU) for long key
 // sequences where latency hiding matters; 2 (256 VGPRs, no spills in the masked tail block) for short ones (cross-attention).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// bench-only ablations (tools/attn_abl.hip builds this file with -DLN3D_ATTN_ABL=n): 1 = no v_exp, 2 = no MFMA, 4 = no barrier/DMA wait
+#ifndef LN3D_ATTN_ABL
+#define LN3D_ATTN_ABL 0
+#endif
+
 template <int DH, int OCC>
 __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   constexpr int NST = DH == 64 ? 4 : 3;           // ring depth
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off + kt * 32 * KROWB + (((2 * ds + hi) ^ kkey_r) << 4));
+        if constexpr (LN3D_ATTN_ABL & 2) { st[kt][ds] += (float)kf[0] * (float)qf[ds][0]; } else
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], st[kt], 0, 0, 0);
       }
     }
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], p.scale_log2, -m_new));
+        const float a = fmaf(st[kt][r], p.scale_log2, -m_new);
+        const float pv = (LN3D_ATTN_ABL & 1) ? a : __builtin_amdgcn_exp2f(a);
         st[kt][r] = pv;
         psum += pv;
       }
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + v_off + dt * 32 * 128 + (((2 * s + hi) ^ vkey_r) << 4));
+        if constexpr (LN3D_ATTN_ABL & 2) { oacc[dt][s] += (float)vf[0] * (float)pb[s][0]; } else
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], oacc[dt], 0, 0, 0);
       }
     }
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     if ((kbv) + NST - 1 < nkb) A_ISSUE((kbv) + NST - 1); /* ring slot of block kb-1: every wave is past it */   \
   }
   for (int kb = 0; kb + 1 < nkb; ++kb) {
-    A_WAIT(kb);
+    if constexpr (!(LN3D_ATTN_ABL & 4)) { A_WAIT(kb); }
     process(kb, std::false_type{});
   }
   A_WAIT(nkb - 1);
@@ -198,19 +208,37 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  const int q = q0 + l31;
-  if (q < p.Nq) {
+  // O goes out through LDS: a lane's accumulator quad is 4 head dims of ONE query and lanes 0-31 are 32 queries, so direct
+  // stores write 16-byte pieces scattered over 32 rows per instruction (partial-line writes, ~1.5 TB/s).  Each wave
+  // transposes 32 queries x 64 dims through its own 8 KB of the retired ring (fp32, 16-byte chunk c of row r at c ^ (r & 15):
+  // conflict-free both ways) and stores complete 128-byte rows of its head.
+  __builtin_amdgcn_s_barrier();                       // every wave is done with the K/V ring
+  {
+    char* stg = smem + wid * 8192;
     const int b = bh / p.H, h = bh - b * p.H;
-    bf16_t* op = p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + 4 * hi;
+    const int rrow = lane >> 4, rc = lane & 15;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+    for (int dp = 0; dp < DH / 64; ++dp) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 o;
-        o.x = pack2bf(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
-        o.y = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dt * 32 + 8 * g) = o;
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = ii * 8 + 2 * g + hi;
+          const int dt = 2 * dp + ii;
+          *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
+              make_float4(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = 4 * it + rrow;
+        const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+        const int q = q0 + row;
+        if (q < p.Nq) {
+          uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + dp * 64 + 4 * rc) = o;
+        }
       }
+    }
   }
 }
 
