@@ -179,8 +179,34 @@ class DiT_TriLatent(DiT):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    def _modulation(self, timesteps, mod, tag):
+        """t -> sincos(256) -> MLP -> SiLU -> adaLN Linear of every block + final layer, all rows of `timesteps` at once."""
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        R = timesteps.shape[0]
+        t32 = timesteps.to(device=mod.device, dtype=torch.float32).contiguous()
+        tf = ws.get(tag + 'tfreq', (R, 256), torch.bfloat16)
+        ops.timestep_embedding(t32, tf, R, 256)
+        th = ws.get(tag + 'th', (R, D), torch.bfloat16)
+        ops.gemm(tf, P['t_w0'], P['t_b0'], ops.EPI_SILU, th)
+        temb = ws.get(tag + 'temb', (R, D), torch.float32)
+        tsilu = ws.get(tag + 'tsilu', (R, D), torch.bfloat16)
+        ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32_SILU, temb, tsilu)
+        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
+
+    def prepare_timesteps(self, t_table):
+        """t_table [n_steps, Bn] (the sampler's whole schedule): the timestep-only part of the network (embedder MLP and the
+        [24*6+2]*D-wide adaLN projection, 306 MB of weights at DiT-L/2) is evaluated for all steps in ONE pass instead of
+        re-streaming those weights every step.  Returns the cache for forward(..., mod_cache=(cache, step))."""
+        dev = next(self.parameters()).device
+        self._ensure_packed(dev)
+        n, Bn = t_table.shape
+        nmod = self.depth * 6 * self.embed_dim + 2 * self.embed_dim
+        mod_all = self._ws.get('mod_all', (n * Bn, nmod), torch.float32)
+        self._modulation(t_table.reshape(-1).to(dev), mod_all, 'ma')
+        return mod_all
+
     def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None,
-                **kwargs):
+                mod_cache=None, **kwargs):
         if get_attr != '':
             return getattr(self, get_attr)
         assert context is not None or context_cache is not None
@@ -199,18 +225,15 @@ class DiT_TriLatent(DiT):
         cc = context_cache if context_cache is not None else self.prepare_context(context)
         assert cc['Bn'] == Bn
 
-        # -- timestep embedding and all adaLN modulations
-        t32 = timesteps.to(device=dev, dtype=torch.float32).contiguous()
-        tf = ws.get('tfreq', (Bn, 256), torch.bfloat16)
-        ops.timestep_embedding(t32, tf, Bn, 256)
-        th = ws.get('th', (Bn, D), torch.bfloat16)
-        ops.gemm(tf, P['t_w0'], P['t_b0'], ops.EPI_SILU, th)
-        temb = ws.get('temb', (Bn, D), torch.float32)
-        tsilu = ws.get('tsilu', (Bn, D), torch.bfloat16)
-        ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32_SILU, temb, tsilu)
+        # -- timestep embedding and all adaLN modulations (or the rows prepared for the whole schedule)
         nmod = depth * 6 * D + 2 * D
-        mod = ws.get('mod', (Bn, nmod), torch.float32)
-        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
+        if mod_cache is not None:
+            mod_all, step = mod_cache
+            mod = mod_all[step * Bn:(step + 1) * Bn]
+            assert mod.shape == (Bn, nmod)
+        else:
+            mod = ws.get('mod', (Bn, nmod), torch.float32)
+            self._modulation(timesteps, mod, 'm')
 
         # -- tokens
         xt = ws.get('x', (M, D), torch.float32)

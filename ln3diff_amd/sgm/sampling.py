@@ -11,6 +11,8 @@ elementwise kernel for denoiser-combine + CFG + Euler update (ln3d_edm_euler_ste
 computed once per call, not once per step.
 """
 import numpy as np
+import os
+
 import torch
 
 from .. import ops
@@ -90,12 +92,20 @@ class EulerEDMSampler:
         x = x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
         t_dev = torch.empty(2 * B, device=dev, dtype=torch.float32)
         s_dev = torch.empty(2 * B, device=dev, dtype=torch.float32)
+        quant = [denoiser.quantize(sigmas[i]) for i in range(n)]
+        mod_all = None
+        if hasattr(network, 'prepare_timesteps') and not os.environ.get('LN3D_NO_MODCACHE'):   # timestep-only sub-network for the whole schedule in one pass
+            t_table = torch.tensor([float(q[1]) for q in quant], dtype=torch.float32)[:, None].expand(n, 2 * B)
+            mod_all = network.prepare_timesteps(t_table)
         for i in range(n):
-            sig, idx = denoiser.quantize(sigmas[i])
+            sig, idx = quant[i]
             c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
             t_dev.fill_(float(idx))
             s_dev.fill_(c_in)
-            eps2 = network(x, t_dev, context_cache=cache, in_scale=s_dev)
+            if mod_all is not None:
+                eps2 = network(x, t_dev, context_cache=cache, in_scale=s_dev, mod_cache=(mod_all, i))
+            else:
+                eps2 = network(x, t_dev, context_cache=cache, in_scale=s_dev)
             ops.edm_euler_step(x, eps2, sig, float(sigmas[i + 1]), float(self.guider.scale))
             if trace is not None:
                 trace.append(x.clone())
