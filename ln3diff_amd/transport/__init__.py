@@ -1,4 +1,4 @@
-"""Flow-matching (SiT transport) ODE sampling on the HIP path.
+"""Flow-matching (SiT transport) ODE / SDE sampling on the HIP path.
 
 Surface of the reference's transport package for the sampling path: create_transport(...),
 Sampler(transport).sample_ode(sampling_method, num_steps, atol, rtol, reverse)(x, model_fn, **kw) -> [T, ...]
@@ -62,6 +62,96 @@ class Sampler:
                     traj.append(x.clone())
             return torch.stack(traj, 0) if return_trajectory else x[None]
         return sample
+
+
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        """transport/transport.py:312-372 + integrators.sde (integrators.py:9-76), Linear path / velocity prediction:
+        drift = v + D(t) * score, score = (t v - x) / (1 - t), t = linspace(0, 1 - last_step_size, num_steps).
+        Every update is an affine combination of device tensors with host-computed scalar coefficients (t is uniform over
+        the batch), i.e. one ln3d_lincomb launch; the Wiener increments are drawn like the reference
+        (torch.randn(x.size()) from the global CPU generator, then moved to the device).  Returns the list of states."""
+        import math
+        if last_step is None:
+            last_step_size = 0.0
+        t1 = 1.0 if last_step_size == 0 else 1 - last_step_size
+        ts = torch.linspace(0.0, t1, num_steps)
+        dt = float(ts[1] - ts[0])
+
+        def D(t):
+            if diffusion_form == "constant":       # the reference hands a Python float to th.sqrt (integrators.py:37)
+                raise TypeError("sqrt(): argument 'input' (position 1) must be Tensor, not float")
+            if diffusion_form == "SBDM":
+                return diffusion_norm * ((1 - t) ** 2 / t + (1 - t)) if t > 0 else float('inf')
+            if diffusion_form in ("sigma", "linear"):
+                return diffusion_norm * (1 - t)
+            if diffusion_form == "decreasing":
+                return 0.25 * (diffusion_norm * math.cos(math.pi * t) + 1) ** 2
+            if diffusion_form == "inccreasing-decreasing":
+                return diffusion_norm * math.sin(math.pi * t) ** 2
+            raise NotImplementedError(f"Diffusion form {diffusion_form} not implemented")
+
+        if sampling_method not in ("Euler", "Heun"):
+            raise NotImplementedError("Smapler type not implemented.")
+        if last_step not in (None, "Mean", "Tweedie", "Euler"):
+            raise NotImplementedError()
+
+        @torch.no_grad()
+        def _sample(init, model_fn, **model_kwargs):
+            dev = init.device
+            x = init.clone().float().contiguous()
+            t_dev = torch.empty(x.shape[0], device=dev, dtype=torch.float32)
+
+            def vel(xx, t):
+                t_dev.fill_(t)
+                return model_fn(xx, t_dev, **model_kwargs).contiguous()
+
+            def drift_coefs(t):                     # sde_drift(x, t) = cv * v + cx * x
+                d = D(t)
+                return 1.0 + d * t / (1 - t), -d / (1 - t)
+
+            xs = []
+            for ti in ts[:-1]:
+                t = float(ti)
+                w = torch.randn(x.size()).to(dev)
+                cw = math.sqrt(2 * D(t)) * math.sqrt(dt)
+                if sampling_method == "Euler":
+                    cv, cx = drift_coefs(t)
+                    v = vel(x, t)
+                    xn = torch.empty_like(x)
+                    ops.lincomb(None, [x, v, w], [1.0 + cx * dt, cv * dt, cw], xn)
+                else:
+                    xhat = torch.empty_like(x)
+                    ops.lincomb(x, [w], [cw], xhat)
+                    cv1, cx1 = drift_coefs(t)
+                    v1 = vel(xhat, t)
+                    xp = torch.empty_like(x)
+                    ops.lincomb(None, [xhat, v1], [1.0 + dt * cx1, dt * cv1], xp)
+                    cv2, cx2 = drift_coefs(t + dt)
+                    v2 = vel(xp, t + dt)
+                    xn = torch.empty_like(x)
+                    # xhat + 0.5 dt (K1 + K2), K1 = cv1 v1 + cx1 xhat, K2 = cv2 v2 + cx2 xp
+                    ops.lincomb(None, [xhat, v1, v2, xp], [1.0 + 0.5 * dt * cx1, 0.5 * dt * cv1, 0.5 * dt * cv2, 0.5 * dt * cx2], xn)
+                x = xn
+                xs.append(x)
+            xl = xs[-1]
+            if last_step is None:
+                x = xl
+            else:
+                v = vel(xl, t1)
+                x = torch.empty_like(xl)
+                if last_step == "Mean":
+                    cv, cx = drift_coefs(t1)
+                    ops.lincomb(None, [xl, v], [1.0 + cx * last_step_size, cv * last_step_size], x)
+                elif last_step == "Euler":
+                    ops.lincomb(xl, [v], [last_step_size], x)
+                else:                                   # Tweedie: x / alpha + sigma^2 / alpha * score
+                    a, sg = t1, 1 - t1
+                    ops.lincomb(None, [xl, v], [1.0 / a - sg * sg / a / (1 - t1), sg * sg / a * t1 / (1 - t1)], x)
+            xs.append(x)
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+        return _sample
 
 
 # ----------------------------------------------------------------------------- adaptive Dormand-Prince 5(4)

@@ -231,3 +231,74 @@ def flow_ode_sample(model_fn, x, num_steps=50, method="euler", **model_kwargs):
         else:
             raise ValueError(method)
     return x
+
+
+def _sde_diffusion(t, form="SBDM", norm=1.0):
+    """transport/path.py:45-67 for the Linear path (alpha = t, sigma = 1 - t): scalar-tensor in, scalar-tensor out."""
+    import math
+    if form == "constant":          # the reference hands a Python float to th.sqrt here (integrators.py:37): TypeError
+        raise TypeError("sqrt(): argument 'input' (position 1) must be Tensor, not float")
+    if form == "SBDM":
+        return norm * ((1 / t) * (1 - t) ** 2 + (1 - t))           # alpha_ratio * sigma^2 - sigma * d_sigma (path.py:35-43)
+    if form == "sigma":
+        return norm * (1 - t)
+    if form == "linear":
+        return norm * (1 - t)
+    if form == "decreasing":
+        return 0.25 * (norm * torch.cos(math.pi * t) + 1) ** 2
+    if form == "inccreasing-decreasing":
+        return norm * torch.sin(math.pi * t) ** 2
+    raise NotImplementedError(form)
+
+
+def flow_sde_sample(model_fn, x, num_steps=250, method="Euler", diffusion_form="SBDM", diffusion_norm=1.0,
+                    last_step="Mean", last_step_size=0.04, **model_kwargs):
+    """transport.Sampler.sample_sde (transport/transport.py:312-372) + integrators.sde (integrators.py:9-76) for the Linear
+    path with velocity prediction (create_transport forces train_eps = sample_eps = 0 there, transport/__init__.py:58-60):
+    drift = v + D * score, score = (t v - x) / (1 - t) (path.py:70-84), t = linspace(0, 1 - last_step_size, num_steps),
+    Euler-Maruyama / stochastic Heun, then the 'Mean' / 'Euler' / 'Tweedie' last step.  Noise: torch.randn(x.size()) from
+    the global CPU generator, once per step, like the reference.  Returns the list of states (len == num_steps)."""
+    if last_step is None:
+        last_step_size = 0.0
+    t1 = 1.0 if last_step_size == 0 else 1 - last_step_size
+    ts = torch.linspace(0.0, t1, num_steps)
+    dt = ts[1] - ts[0]
+    tb = lambda t: torch.ones(x.size(0)) * t
+
+    def score(xx, t, v):
+        return (t * v - xx) / (1 - t)
+
+    def sde_drift(xx, t):
+        v = model_fn(xx, tb(t), **model_kwargs)
+        return v + _sde_diffusion(t, diffusion_form, diffusion_norm) * score(xx, t, v)
+
+    xs = []
+    for ti in ts[:-1]:
+        w = torch.randn(x.size())
+        dw = w * torch.sqrt(dt)
+        if method == "Euler":
+            mean_x = x + sde_drift(x, ti) * dt
+            x = mean_x + torch.sqrt(2 * _sde_diffusion(ti, diffusion_form, diffusion_norm)) * dw
+        elif method == "Heun":
+            xhat = x + torch.sqrt(2 * _sde_diffusion(ti, diffusion_form, diffusion_norm)) * dw
+            k1 = sde_drift(xhat, ti)
+            xp = xhat + dt * k1
+            k2 = sde_drift(xp, ti + dt)
+            x = xhat + 0.5 * dt * (k1 + k2)
+        else:
+            raise NotImplementedError(method)
+        xs.append(x)
+    tl = torch.as_tensor(t1, dtype=torch.float32)
+    if last_step is None:
+        x = xs[-1]
+    elif last_step == "Mean":
+        x = xs[-1] + sde_drift(xs[-1], tl) * last_step_size
+    elif last_step == "Euler":
+        x = xs[-1] + model_fn(xs[-1], tb(tl), **model_kwargs) * last_step_size
+    elif last_step == "Tweedie":
+        v = model_fn(xs[-1], tb(tl), **model_kwargs)
+        x = xs[-1] / tl + ((1 - tl) ** 2) / tl * score(xs[-1], tl, v)
+    else:
+        raise NotImplementedError(last_step)
+    xs.append(x)
+    return xs

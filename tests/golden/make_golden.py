@@ -257,6 +257,18 @@ def sec_i23d():
         check(f'flow {method} num_steps={steps} final latent', y_or, y_ref, 2e-4)
         save(f'flow_tiny_{method}{steps}', final=y_ref)
 
+    # SDE samplers (transport.Sampler.sample_sde: Euler-Maruyama / Heun; noise from the global CPU generator)
+    for method, steps, form, last in (('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'), ('Euler', 12, 'decreasing', 'Tweedie')):
+        fn = Sampler(tr).sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=0.7, last_step=last,
+                                    last_step_size=0.04, num_steps=steps)
+        torch.manual_seed(1234)
+        y_ref = fn(zs.clone(), m.forward_with_cfg, context=context, cfg_scale=4.0)[-1].chunk(2)[0]
+        torch.manual_seed(1234)
+        y_or = osamp.flow_sde_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], kw['cfg_scale'], 2),
+                                     zs.clone(), steps, method, form, 0.7, last, 0.04, context=context, cfg_scale=4.0)[-1].chunk(2)[0]
+        check(f'flow SDE {method} {form} {last} num_steps={steps} final latent', y_or, y_ref, 2e-4)
+        save(f'sde_tiny_{method.lower()}{steps}_{form}_{last.lower()}', final=y_ref)
+
     hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
     m = build_i23d(hidden, depth, heads)
     sd, shapes = load_synth(m, 0)

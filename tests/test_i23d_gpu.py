@@ -65,6 +65,31 @@ def test_flow_matching_ode_vs_reference_golden(hip_lib, method, steps):
     assert e < 5e-2, e
 
 
+@pytest.mark.parametrize("method,steps,form,last", [('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'),
+                                                    ('Euler', 12, 'decreasing', 'Tweedie')])
+def test_flow_matching_sde_vs_reference_golden(hip_lib, method, steps, form, last):
+    from ln3diff_amd.synth import synth_input
+    from ln3diff_amd.transport import Sampler, create_transport
+    g = golden(f'sde_tiny_{method.lower()}{steps}_{form}_{last.lower()}')
+    m = _build(128, 2, 2)
+    load_synth(m, 0)
+    m = m.cuda()
+    z = synth_input('z', (2, 12, 32, 32), 42).cuda()
+    cond = {'crossattn': synth_input('ca', (2, 256, 2048), 42).cuda(), 'vector': synth_input('v', (2, 768), 42).cuda()}
+    ctx = {k: torch.cat([v, torch.zeros_like(v)], 0) for k, v in cond.items()}
+    cache = m.prepare_context(ctx)
+    fn = Sampler(create_transport(snr_type='lognorm')).sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=0.7,
+                                                                  last_step=last, last_step_size=0.04, num_steps=steps)
+    torch.manual_seed(1234)                     # same Wiener increments as the reference run (global CPU generator)
+    xs = fn(torch.cat([z, z]), m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)
+    assert len(xs) == steps
+    e = rel_l2(xs[-1].chunk(2)[0].cpu(), g['final'])
+    print('sde', method, steps, form, last, e)
+    assert e < 5e-2, e
+    with pytest.raises(TypeError):
+        Sampler(create_transport()).sample_sde(diffusion_form='constant', num_steps=3)(z, m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)
+
+
 def test_dopri5_converges_to_fixed_step_solution(hip_lib):
     """Adaptive Dormand-Prince (parity unpinned: torchdiffeq is absent) must agree with a fine fixed-step Heun solution of
     the same ODE, and tighter tolerances must get closer."""

@@ -87,6 +87,22 @@ def test_oracle_flow_heun_matches_reference_golden():
     assert rel_l2(y, g['final']) < 1e-4
 
 
+@pytest.mark.parametrize("method,steps,form,last", [('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'),
+                                                    ('Euler', 12, 'decreasing', 'Tweedie')])
+def test_oracle_flow_sde_matches_reference_golden(method, steps, form, last):
+    g = golden(f'sde_tiny_{method.lower()}{steps}_{form}_{last.lower()}')
+    sd = _sd_from_manifest(golden('i23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 42)
+    cond = {'crossattn': synth_input('ca', (2, 256, 2048), 42), 'vector': synth_input('v', (2, 768), 42)}
+    ctx = {k: torch.cat([v, torch.zeros_like(v)], 0) for k, v in cond.items()}
+    torch.manual_seed(1234)
+    y = osamp.flow_sde_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], 4.0, 2),
+                              torch.cat([z, z]), steps, method, form, 0.7, last, 0.04, context=ctx)[-1].chunk(2)[0]
+    assert rel_l2(y, g['final']) < 1e-4
+    with pytest.raises(TypeError):          # the reference's 'constant' form is broken (sqrt of a float): same error here
+        osamp.flow_sde_sample(lambda x, t, **kw: x, torch.zeros(1, 2), 3, 'Euler', 'constant')
+
+
 def test_schedule_tables():
     assert osamp.space_timesteps(1000, 'ddim250') == set(range(0, 1000, 4))
     s50 = sorted(osamp.space_timesteps(1000, '50'))
