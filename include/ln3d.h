@@ -43,7 +43,8 @@ enum {
   LN3D_EPI_SILU = 4,       /* out0 bf16 = silu(.)                                          */
   LN3D_EPI_GATE_RES = 5,   /* out0 f32 [M,ldo] += gate * (.) ; optional out1 bf16 copy      */
   LN3D_EPI_HEADS = 6,      /* split columns into heads: out{0,1,2} bf16, see below          */
-  LN3D_EPI_F32_SILU = 7    /* out0 f32 raw and out1 bf16 = silu(.)                           */
+  LN3D_EPI_F32_SILU = 7,   /* out0 f32 raw and out1 bf16 = silu(.)                           */
+  LN3D_EPI_QUICK_GELU = 8  /* out0 bf16 = x * sigmoid(1.702 x)  (CLIP text MLP, hidden_act quick_gelu) */
 };
 
 typedef struct {
@@ -81,8 +82,17 @@ typedef struct {
   int B, H, Nq, Nq_pad, Nk, Nk_pad, Dh;
   int64_t ldo;
   float scale;
+  int causal;              /* 1: query i attends keys <= i (CLIP text tower); 0: full attention */
 } ln3d_attn_args;
 int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------- text conditioner helpers (CLIP-L text tower =
+ * sgm/modules/encoders/modules.py:347-405 -> HuggingFace CLIPTextModel)
+ * out[b*T + t, :] = tok_emb[ids[b*T + t], :] + pos_emb[t, :]   (f32) */
+int ln3d_embed_tokens(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* out, int B, int T, int D, int vocab,
+                      void* stream);
+/* affine LayerNorm f32 -> f32 (final_layer_norm; last_hidden_state / pooled stay fp32), D % 128 == 0, D <= 1152 */
+int ln3d_layernorm_f32(const float* x, const float* w, const float* b, float* y, int64_t rows, int D, float eps, void* stream);
 
 /* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
  * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40) */

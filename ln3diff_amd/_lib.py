@@ -14,10 +14,10 @@ SYMBOLS = [
     "ln3d_add_act_cast", "ln3d_cast_f32_bf16", "ln3d_patch_embed", "ln3d_final_layer",
     "ln3d_edm_euler_step", "ln3d_ddpm_step", "ln3d_flow_euler_step", "ln3d_axpby",
     "ln3d_planes_to_channel_last", "ln3d_planes_to_nchw", "ln3d_render_triplane",
-    "ln3d_query_points", "ln3d_groupnorm_swish", "ln3d_im2col3x3", "ln3d_patch_embed_triplane", "ln3d_tile_rows", "ln3d_add_table_rows", "ln3d_cfg_combine_dup", "ln3d_ddim_step", "ln3d_mesh_count", "ln3d_mesh_emit", "ln3d_lincomb", "ln3d_err_ratio_sq",
+    "ln3d_query_points", "ln3d_groupnorm_swish", "ln3d_im2col3x3", "ln3d_patch_embed_triplane", "ln3d_tile_rows", "ln3d_add_table_rows", "ln3d_cfg_combine_dup", "ln3d_ddim_step", "ln3d_mesh_count", "ln3d_mesh_emit", "ln3d_lincomb", "ln3d_err_ratio_sq", "ln3d_embed_tokens", "ln3d_layernorm_f32",
 ]
 
-EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU = range(8)
+EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU = range(9)
 RENDER_SCRATCH_FLOATS = 4096
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp),
                 ("B", i32), ("H", i32), ("Nq", i32), ("Nq_pad", i32), ("Nk", i32), ("Nk_pad", i32),
-                ("Dh", i32), ("ldo", i64), ("scale", f32)]
+                ("Dh", i32), ("ldo", i64), ("scale", f32), ("causal", i32)]
 
 
 class NormArgs(C.Structure):
@@ -76,7 +76,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 1
+    assert L.ln3d_abi_version() == 2
     return True
 
 

@@ -19,6 +19,7 @@ struct AttnP {
   int B, H, Nq, Nq_pad, Nk, Nk_pad;
   int64_t ldo;
   float scale_log2;
+  int causal;
 };
 
 #define KVB 64
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key_base + kt * 32 + (r & 3) + 8 * (r >> 2);
-          st[kt][r] = key < p.Nk ? st[kt][r] : -3.0e38f;
+          st[kt][r] = (key < p.Nk && (!p.causal || key <= q0 + l31)) ? st[kt][r] : -3.0e38f;
         }
     }
     float mx = -3.0e38f;
@@ -200,10 +201,11 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   }
   for (int kb = 0; kb + 1 < nkb; ++kb) {
     if constexpr (!(LN3D_ATTN_ABL & 4)) { A_WAIT(kb); }
-    process(kb, std::false_type{});
+    if (p.causal) process(kb, std::true_type{});       // masked variant (key <= query); wave-uniform branch
+    else process(kb, std::false_type{});
   }
   A_WAIT(nkb - 1);
-  if ((p.Nk & (KVB - 1)) != 0) process(nkb - 1, std::true_type{});
+  if ((p.Nk & (KVB - 1)) != 0 || p.causal) process(nkb - 1, std::true_type{});
   else process(nkb - 1, std::false_type{});
 
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -265,6 +267,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nq_pad = a->Nq_pad; p.Nk = a->Nk; p.Nk_pad = a->Nk_pad;
   p.ldo = a->ldo;
   p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.causal = a->causal ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (a->Dh == 64) return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
   if (a->Dh == 128) return launch_attn<128, 2>(p, s);

@@ -132,6 +132,56 @@ extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
   return ln3d_check_launch();
 }
 
+// ------------------------------------------------------------------ text conditioner helpers
+__global__ void embed_tokens_kernel(const int32_t* ids, const float4* tok, const float4* pos, float4* out, int64_t n4, int T, int D4, int vocab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int64_t row = i / D4; const int d = (int)(i - row * D4);
+  int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4 a = tok[(int64_t)id * D4 + d], b = pos[(int64_t)(row % T) * D4 + d];
+  out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+extern "C" int ln3d_embed_tokens(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* out, int B, int T, int D, int vocab,
+                                 void* stream) {
+  if (!ids || !tok_emb || !pos_emb || !out || B <= 0 || T <= 0 || D % 4 || vocab <= 0) return LN3D_ERR_BAD_ARG;
+  const int64_t n4 = (int64_t)B * T * (D / 4);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                     (const float4*)tok_emb, (const float4*)pos_emb, (float4*)out, n4, T, D / 4, vocab);
+  return ln3d_check_launch();
+}
+
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* x, const float* w, const float* b, float* y, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = D / 128;
+  const float* xr = x + row * D;
+  float2 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[i].x + v[i].y; }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { const float a = v[i].x - mean, c = v[i].y - mean; q += a * a + c * c; }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const int d = i * 128 + lane * 2;
+      const float2 ww = w ? *reinterpret_cast<const float2*>(w + d) : make_float2(1.f, 1.f);
+      const float2 bb = b ? *reinterpret_cast<const float2*>(b + d) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(y + row * D + d) = make_float2((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y);
+    }
+}
+extern "C" int ln3d_layernorm_f32(const float* x, const float* w, const float* b, float* y, int64_t rows, int D, float eps, void* stream) {
+  if (!x || !y || rows <= 0 || D % 128 != 0 || D > 128 * MAXV) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, rows, D, eps);
+  return ln3d_check_launch();
+}
+
 // ------------------------------------------------------------------ small elementwise
 __global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,4 +577,4 @@ extern "C" const char* ln3d_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int ln3d_abi_version(void) { return 1; }
+extern "C" int ln3d_abi_version(void) { return 2; }

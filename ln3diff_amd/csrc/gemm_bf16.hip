@@ -46,7 +46,8 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
   if constexpr (EPI == LN3D_EPI_F32) {
     *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb) = make_float4(v0, v1, v2, v3);
   } else if constexpr (EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH ||
-                       EPI == LN3D_EPI_SILU) {
+                       EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU) {
+    if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
     if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
     if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
     if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
@@ -277,6 +278,7 @@ struct RunEpi {
       if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
       if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
       if constexpr (EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_F32_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+      if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
       if constexpr (EPI != LN3D_EPI_F32) {
         uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
         *reinterpret_cast<uint2*>((bf16_t*)(EPI == LN3D_EPI_F32_SILU ? p.out1 : p.out0) + off) = o;
@@ -575,6 +577,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
     case LN3D_EPI_GELU_ERF: return run_cfg<LN3D_EPI_GELU_ERF>(p, s, cfg);
     case LN3D_EPI_GELU_TANH: return run_cfg<LN3D_EPI_GELU_TANH>(p, s, cfg);
     case LN3D_EPI_SILU: return run_cfg<LN3D_EPI_SILU>(p, s, cfg);
+    case LN3D_EPI_QUICK_GELU: return run_cfg<LN3D_EPI_QUICK_GELU>(p, s, cfg);
     case LN3D_EPI_GATE_RES: return run_cfg<LN3D_EPI_GATE_RES>(p, s, cfg);
     case LN3D_EPI_F32_SILU:
       if (!a->out1) return LN3D_ERR_BAD_ARG;

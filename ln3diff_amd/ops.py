@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES,  # noqa: F401
-                   EPI_HEADS, EPI_F32_SILU)
+                   EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU)
 
 
 def _p(t):
@@ -43,13 +43,14 @@ def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, 
     L.check(L.lib().ln3d_gemm_bf16(C.byref(a), _stream()), "gemm")
 
 
-def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None):
+def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causal=False):
     _chk_dev(q, k, vt, out)
     a = L.AttnArgs()
     a.Q, a.K, a.Vt, a.O = _p(q), _p(k), _p(vt), _p(out)
     a.B, a.H, a.Nq, a.Nq_pad, a.Nk, a.Nk_pad, a.Dh = B, H, Nq, Nq_pad, Nk, Nk_pad, Dh
     a.ldo = H * Dh
     a.scale = float(scale if scale is not None else Dh ** -0.5)
+    a.causal = int(bool(causal))
     L.check(L.lib().ln3d_attention_bf16(C.byref(a), _stream()), "attention")
 
 
@@ -192,3 +193,12 @@ def lincomb(y, ks, cs, out):
 def err_ratio_sq(err, y0, y1, atol, rtol, acc):
     L.check(L.lib().ln3d_err_ratio_sq(_p(err), _p(y0), _p(y1), C.c_float(atol), C.c_float(rtol), _p(acc),
                                       C.c_int64(err.numel()), _stream()), "err_ratio_sq")
+
+
+def embed_tokens(ids, tok_emb, pos_emb, out, B, T, D):
+    assert ids.dtype == torch.int32
+    L.check(L.lib().ln3d_embed_tokens(_p(ids), _p(tok_emb), _p(pos_emb), _p(out), B, T, D, tok_emb.shape[0], _stream()), "embed_tokens")
+
+
+def layernorm_f32(x, w, b, y, rows, D, eps=1e-5):
+    L.check(L.lib().ln3d_layernorm_f32(_p(x), _p(w), _p(b), _p(y), C.c_int64(rows), D, C.c_float(eps), _stream()), "layernorm_f32")

@@ -10,10 +10,24 @@ TRIPLANE_SCALING_DIVIDER = 0.96806      # nsr/train_util_diffusion.py:188
 
 
 class T23DPipeline:
-    def __init__(self, dit, decoder, num_steps=250, cfg_scale=6.5):
-        self.dit, self.decoder = dit, decoder
+    def __init__(self, dit, decoder, num_steps=250, cfg_scale=6.5, conditioner=None):
+        self.dit, self.decoder, self.conditioner = dit, decoder, conditioner
         self.sampler = EulerEDMSampler(num_steps=num_steps, guider=VanillaCFG(cfg_scale))
         self.denoiser = DiscreteDenoiser()
+
+    @torch.no_grad()
+    def encode_prompts(self, captions, uc_captions=None):
+        """GeneralConditioner semantics for the T23D config (sgm/modules/encoders/modules.py:80-191,
+        sgm/configs/txt2img-clipl-compat.yaml): one FrozenCLIPEmbedder on key 'caption' ->
+        cond = {'crossattn': last_hidden_state, 'vector': pooled}; uc = the same for the legacy ucg value "" (or the ids
+        passed in uc_captions).  captions: list of strings (needs the BPE vocabulary) or int token ids [B, 77]."""
+        assert self.conditioner is not None, "construct the pipeline with conditioner=FrozenCLIPEmbedder(...)"
+        z, pooled = self.conditioner(captions)
+        B = z.shape[0]
+        if uc_captions is None:
+            uc_captions = [""] * B
+        zu, pu = self.conditioner(uc_captions)
+        return {'crossattn': z, 'vector': pooled}, {'crossattn': zu.clone(), 'vector': pu.clone()}
 
     @torch.no_grad()
     def sample_latent(self, z, cond, uc):

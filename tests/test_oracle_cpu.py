@@ -161,3 +161,14 @@ def test_oracle_ddim_matches_reference_golden():
     y = osamp.ddim_sample_loop(lambda x, t, cc: odit.t23d_forward(sd, x, t, cc, 2), z, c, osamp.SpacedTables('ddim25'),
                                float(g['eta']), float(g['scale']), None, noises)
     assert rel_l2(y, g['final']) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_eos"])
+def test_oracle_clip_text_matches_transformers_golden(name):
+    import json
+    from oracle import clip_text as oclip
+    g = golden(f'clip_text_{name}')
+    shapes = {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
+    sd = synth_state_dict(shapes, 0)
+    last, pooled = oclip.clip_text_forward(sd, torch.from_numpy(g['ids']).long(), int(g['heads']), int(g['eos_token_id']))
+    assert rel_l2(last, g['last']) < 1e-5 and rel_l2(pooled, g['pooled']) < 1e-5
