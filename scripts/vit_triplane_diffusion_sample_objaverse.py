@@ -62,25 +62,8 @@ def create_argparser():
 
 
 def load_checkpoint(path, dit, dec):
-    if path.endswith(".safetensors"):
-        from safetensors.torch import load_file
-        sd = load_file(path)
-    else:
-        sd = torch.load(path, map_location="cpu")
-    def sub(prefixes, module):
-        own = module.state_dict()
-        out = {}
-        for k in own:
-            for p in prefixes:
-                if p + k in sd and tuple(sd[p + k].shape) == tuple(own[k].shape):
-                    out[k] = sd[p + k]
-                    break
-        missing = [k for k in own if k not in out]
-        if missing:
-            raise RuntimeError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:5]}")
-        module.load_state_dict(out)
-    sub(["ddpm_model.", "module.", ""], dit)
-    sub(["rec_model.decoder.", "decoder.", "auto_encoder.decoder.", ""], dec)
+    from ln3diff_amd.checkpoint import load_checkpoint as _load
+    return _load(path, dit=dit, decoder=dec)
 
 
 def main():

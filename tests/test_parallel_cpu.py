@@ -68,3 +68,29 @@ def test_shard_range_partitions():
             spans = [shard_range(total, r, world) for r in range(world)]
             cover = [i for lo, hi in spans for i in range(lo, hi)]
             assert cover == list(range(total))
+
+
+def test_checkpoint_loader_prefixes_and_strictness(tmp_path):
+    """ln3diff_amd.checkpoint: reference-named tensors under the released prefixes load strictly; a shape mismatch raises."""
+    import torch
+    from safetensors.torch import save_file
+    from ln3diff_amd.checkpoint import load_checkpoint
+    from ln3diff_amd.dit.dit_trilatent import DiT_TriLatent
+    from ln3diff_amd.synth import synth_state_dict
+    m = DiT_TriLatent(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, context_dim=768,
+                      num_classes=0, learn_sigma=False, roll_out=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert 'blocks.0.mlp.mlp.0.weight' in shapes and 'blocks.0.mlp.mlp.1.bias' in shapes      # xformers FusedMLP naming
+    sd = synth_state_dict({k: v for k, v in shapes.items() if 'pos_embed' not in k}, 3)
+    sd.update({k: v.clone() for k, v in m.state_dict().items() if 'pos_embed' in k})     # computed buffer, saved as is
+    f = str(tmp_path / 'ck.safetensors')
+    save_file({'ddpm_model.' + k: v.contiguous() for k, v in sd.items()}, f)
+    rep = load_checkpoint(f, dit=m)
+    assert rep['dit'] == {'ddpm_model.': len(shapes)}
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    bad = dict(sd); bad['final_layer.linear.bias'] = torch.zeros(3)
+    f2 = str(tmp_path / 'bad.pt')
+    torch.save({'module.' + k: v for k, v in bad.items()}, f2)
+    import pytest
+    with pytest.raises(RuntimeError):
+        load_checkpoint(f2, dit=m)
