@@ -82,7 +82,7 @@ typedef struct {
   int B, H, Nq, Nq_pad, Nk, Nk_pad, Dh;
   int64_t ldo;
   float scale;
-  int causal;              /* 1: query i attends keys <= i (CLIP text tower); 0: full attention */
+  int causal;              /* 1: query i attends keys <= i (CLIP text tower; Dh 64 and Nk <= 128 only); 0: full attention */
 } ln3d_attn_args;
 int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream);
 

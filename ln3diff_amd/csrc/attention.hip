@@ -10,6 +10,7 @@
 //    permutation of the accumulator layout is baked into the V^T memory layout (see attn_kernel).
 //  * softmax in the log2 domain: one FMA + one v_exp_f32 per score; the O rescale is skipped, wave-uniformly and
 //    exactly, when no row maximum moved.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "../../include/ln3d.h"
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key_base + kt * 32 + (r & 3) + 8 * (r >> 2);
-          st[kt][r] = (key < p.Nk && (!p.causal || key <= q0 + l31)) ? st[kt][r] : -3.0e38f;
+          st[kt][r] = key < p.Nk ? st[kt][r] : -3.0e38f;
         }
     }
     float mx = -3.0e38f;
@@ -201,11 +202,10 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   }
   for (int kb = 0; kb + 1 < nkb; ++kb) {
     if constexpr (!(LN3D_ATTN_ABL & 4)) { A_WAIT(kb); }
-    if (p.causal) process(kb, std::true_type{});       // masked variant (key <= query); wave-uniform branch
-    else process(kb, std::false_type{});
+    process(kb, std::false_type{});
   }
   A_WAIT(nkb - 1);
-  if ((p.Nk & (KVB - 1)) != 0 || p.causal) process(nkb - 1, std::true_type{});
+  if ((p.Nk & (KVB - 1)) != 0) process(nkb - 1, std::true_type{});
   else process(nkb - 1, std::false_type{});
 
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -244,6 +244,193 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short key sequences (Nk <= 128: the 77-token text context of every cross-attention, the CLIP text tower), Dh = 64.
+// The general kernel above is latency-bound there (ring prologue, a barrier per block, 768 workgroups on 512 slots).  Here a
+// workgroup is 4 waves = 256 queries of one (batch, head), every wave takes two 32-query tiles in turn; K and V^T of the whole
+// head (2 x 16 KB, same tile images and swizzle as the ring stages) are DMA'd once, one barrier, then softmax is a single
+// pass over the <= 128 scores a lane holds (no online rescale).  48 KB LDS and <= 168 VGPRs: three workgroups per CU, so
+// B*H*ceil(Nq/256) = 768 workgroups of DiT-L/2 are exactly one round on 256 CUs.
+template <int QT>   // query tiles (of 32) per wave: the workgroup covers 128 * QT queries
+__global__ __launch_bounds__(256, 3) void attn_short_kernel(AttnP p) {
+  constexpr int DH = 64, KROWB = 128, KTILE = KVB * KROWB, VTILE = DH * 128, STAGEB = KTILE + VTILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
+  const bf16_t* Kg = p.K + (int64_t)bh * p.Nk_pad * DH;
+  const bf16_t* Vg = p.Vt + (int64_t)bh * DH * p.Nk_pad;
+  const int nkb = (p.Nk + KVB - 1) / KVB;            // 1 or 2
+
+  // K / V^T of the head: tile image j (1 KB each, 8 per tile) exactly as in attn_kernel; wave w issues j = w and w + 4
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    if (kb < nkb) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = wid + 4 * i;
+        const int krow = j * 8 + lane / 8, kcp = lane % 8;
+        const bf16_t* ks = Kg + (int64_t)(kb * KVB + krow) * DH + ((kcp ^ ((krow >> 1) & 7)) * 8);
+        const int vrow = j * 8 + (lane >> 3), vcp = lane & 7;
+        const bf16_t* vs = Vg + (int64_t)vrow * p.Nk_pad + kb * KVB + ((vcp ^ ((vrow >> 1) & 7)) * 8);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)ks, (lds_void_t*)(smem + kb * STAGEB + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)vs, (lds_void_t*)(smem + kb * STAGEB + KTILE + j * 1024), 16, 0, 0);
+      }
+    }
+  }
+  // Q tiles of this wave: 32 rows x 128 B are contiguous in memory, so they are read with fully coalesced 16-byte loads (a
+  // fragment-shaped read would touch 32 rows x 32 B per instruction) and re-shaped through the wave's private 4 KB of LDS
+  // (K-style swizzle); the same 4 KB later transposes O so that it leaves as complete 128-byte rows.
+  char* wreg = smem + 2 * STAGEB + wid * 4096;
+  uint4 qraw[QT][4];
+#pragma unroll
+  for (int it = 0; it < QT; ++it) {
+    const int q0 = blockIdx.x * (128 * QT) + (QT * wid + it) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = q0 + 8 * i + (lane >> 3); row = row < p.Nq_pad ? row : p.Nq_pad - 1;
+      qraw[it][i] = *reinterpret_cast<const uint4*>(Qg + (int64_t)row * DH + (lane & 7) * 8);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int kkey_r = (l31 >> 1) & 7, k_off = l31 * KROWB;
+  const int vkey_r = (l31 >> 1) & 7, v_off = KTILE + l31 * 128;
+  const int b = bh / p.H, h = bh - b * p.H;
+  if constexpr (LN3D_ATTN_ABL & 8) {                   // bench-only: loads + stores, no compute
+#pragma unroll
+    for (int it = 0; it < QT; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = blockIdx.x * (128 * QT) + (QT * wid + it) * 32 + 8 * i + (lane >> 3);
+        if (q < p.Nq) *reinterpret_cast<uint4*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + (lane & 7) * 8) = qraw[it][i];
+      }
+    return;
+  }
+#pragma unroll 1
+  for (int it = 0; it < QT; ++it) {
+    const int q0 = blockIdx.x * (128 * QT) + (QT * wid + it) * 32;
+    if (q0 >= p.Nq) break;                            // wave-uniform
+    bf16x8 qc[4];
+    {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const uint4 v = (QT > 1 && it) ? qraw[QT - 1][i] : qraw[0][i];
+        *reinterpret_cast<uint4*>(wreg + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds)
+        qc[ds] = *reinterpret_cast<const bf16x8*>(wreg + l31 * 128 + (((2 * ds + hi) ^ kkey_r) << 4));
+    }
+    f32x16 st[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][kt][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb < nkb) {
+        const char* sb = smem + kb * STAGEB;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off + kt * 32 * KROWB + (((2 * ds + hi) ^ kkey_r) << 4));
+            st[kb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qc[ds], st[kb][kt], 0, 0, 0);
+          }
+      }
+    }
+    // mask (tail keys, keys of an absent second block, causal) and the row maximum
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * KVB + 4 * hi + kt * 32 + (r & 3) + 8 * (r >> 2);
+          const bool ok = key < p.Nk && (!p.causal || key <= q0 + l31);
+          st[kb][kt][r] = ok ? st[kb][kt][r] : -3.0e38f;
+          mx = fmaxf(mx, st[kb][kt][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m = mx * p.scale_log2;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][kt][r], p.scale_log2, -m));
+          st[kb][kt][r] = pv;
+          psum += pv;
+        }
+    const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb < nkb) {
+        const char* sb = smem + kb * STAGEB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          union { uint32_t u[4]; bf16x8 v; } cv;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            cv.u[jj] = pack2bf(st[kb][s >> 1][8 * (s & 1) + 2 * jj], st[kb][s >> 1][8 * (s & 1) + 2 * jj + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + v_off + dt * 32 * 128 + (((2 * s + hi) ^ vkey_r) << 4));
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, cv.v, oacc[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // O: bf16 through the wave's 4 KB (8-byte chunk c of row r at c ^ (r & 15)), out as 16 bytes per lane = whole 128-byte rows
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 o;
+        o.x = pack2bf(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+        o.y = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        const int c8 = dt * 8 + 2 * g + hi;
+        *reinterpret_cast<uint2*>(wreg + l31 * 128 + ((c8 ^ (l31 & 15)) << 3)) = o;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + (lane >> 3), c16 = lane & 7;
+      // chunks 2*c16 and 2*c16+1 of row r sit in one aligned 16-byte slot, swapped when r is odd
+      uint4 v = *reinterpret_cast<const uint4*>(wreg + r * 128 + ((c16 ^ ((r & 15) >> 1)) << 4));
+      if (r & 1) { const uint32_t t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+      const int q = q0 + r;
+      if (q < p.Nq) *reinterpret_cast<uint4*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + c16 * 8) = v;
+    }
+  }
+}
+
+static int launch_attn_short(const AttnP& p, hipStream_t s) {
+  // one query tile per wave (128 queries per workgroup): twice the workgroups, so load, compute and store phases of
+  // different workgroups overlap on a CU (the kernel is a latency-bound stream of Q in / O out); LN3D_ATTN_QT=2 for A/B runs
+  const char* qt = getenv("LN3D_ATTN_QT");
+  if (qt && qt[0] == '2') {
+    hipLaunchKernelGGL(attn_short_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.H), dim3(256), 2 * (KVB * 128 + 64 * 128) + 4 * 4096, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_short_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.H), dim3(256), 2 * (KVB * 128 + 64 * 128) + 4 * 4096, s, p);
+  }
+  return ln3d_check_launch();
+}
+
 template <int DH, int OCC>
 static int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NST = DH == 64 ? 4 : 3;
@@ -269,7 +456,13 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.causal = a->causal ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->Dh == 64) return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
+  // causal masking exists in the short-sequence kernel only (its one user is the 77-token CLIP text tower)
+  if (a->causal && !(a->Dh == 64 && a->Nk <= 128)) return LN3D_ERR_UNSUPPORTED;
+  if (a->Dh == 64) {
+    const char* force = getenv("LN3D_ATTN_SHORT");        // bench-only: 0 = general kernel for short keys too
+    if (a->Nk <= 128 && (a->causal || !(force && force[0] == '0'))) return launch_attn_short(p, s);
+    return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
+  }
   if (a->Dh == 128) return launch_attn<128, 2>(p, s);
   return LN3D_ERR_UNSUPPORTED;
 }
