@@ -44,7 +44,14 @@ enum {
   LN3D_EPI_GATE_RES = 5,   /* out0 f32 [M,ldo] += gate * (.) ; optional out1 bf16 copy      */
   LN3D_EPI_HEADS = 6,      /* split columns into heads: out{0,1,2} bf16, see below          */
   LN3D_EPI_F32_SILU = 7,   /* out0 f32 raw and out1 bf16 = silu(.)                           */
-  LN3D_EPI_QUICK_GELU = 8  /* out0 bf16 = x * sigmoid(1.702 x)  (CLIP text MLP, hidden_act quick_gelu) */
+  LN3D_EPI_QUICK_GELU = 8, /* out0 bf16 = x * sigmoid(1.702 x)  (CLIP text MLP, hidden_act quick_gelu) */
+  LN3D_EPI_CROSS_ATTN = 9  /* the GEMM is a cross-attention query projection (no bias) and the attention over a SHORT cached
+                            * context runs in its epilogue: out0 bf16 [M, ldo] = softmax(ctx_scale * q_h K_h^T) V_h per head of
+                            * 64 features, q never leaving the accumulators.  out1 = K cache bf16 [M/tokens, heads, ctx_pad, 64]
+                            * with the 64 head dims of every row stored in the 16-group order [0-3, 8-11, 4-7, 12-15];
+                            * out2 = V^T cache bf16 [M/tokens, heads, 64, ctx_pad] (key order as for ln3d_attention_bf16).
+                            * Requires head_dim 64, N = heads*64, tokens % 192 == 0, ctx_keys <= 96, ctx_pad % 64 == 0.
+                            * (TextCondDiTBlock cross-attention, dit/dit_models_xformers.py:298-323 + ldm/modules/attention.py:278) */
 };
 
 typedef struct {
@@ -61,6 +68,8 @@ typedef struct {
    *   which w writes out{w}: layout [B, heads, tok_pad, head_dim] if !(transpose_mask>>w & 1)
    *   else [B, heads, head_dim, tok_pad] with tokens key-permuted inside 16-groups (V^T for ln3d_attention_bf16). */
   int tokens; int tok_pad; int heads; int head_dim; int transpose_mask;
+  int ctx_keys, ctx_pad;   /* CROSS_ATTN: context length (<= 96) and its padded row count in the K / V^T caches */
+  float ctx_scale;         /* CROSS_ATTN: softmax scale (head_dim^-0.5) */
   int head_dim_pad;   /* HEADS: destination head size (>= head_dim; 0 = head_dim).  DiT-XL/2 (head_dim 72) writes into
                          128-wide zero-initialised heads so that ln3d_attention_bf16 (Dh 64/128) serves it */
 } ln3d_gemm_args;

@@ -17,7 +17,7 @@ SYMBOLS = [
     "ln3d_query_points", "ln3d_groupnorm_swish", "ln3d_im2col3x3", "ln3d_patch_embed_triplane", "ln3d_tile_rows", "ln3d_add_table_rows", "ln3d_cfg_combine_dup", "ln3d_ddim_step", "ln3d_mesh_count", "ln3d_mesh_emit", "ln3d_lincomb", "ln3d_err_ratio_sq", "ln3d_embed_tokens", "ln3d_layernorm_f32",
 ]
 
-EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU = range(9)
+EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU, EPI_CROSS_ATTN = range(10)
 RENDER_SCRATCH_FLOATS = 4096
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("out0", vp), ("out1", vp), ("out2", vp), ("ldo", i64),
                 ("gate", vp), ("gate_rows", i32), ("gate_ld", i64),
                 ("tokens", i32), ("tok_pad", i32), ("heads", i32), ("head_dim", i32),
-                ("transpose_mask", i32), ("head_dim_pad", i32)]
+                ("transpose_mask", i32), ("ctx_keys", i32), ("ctx_pad", i32), ("ctx_scale", f32), ("head_dim_pad", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -76,7 +76,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 2
+    assert L.ln3d_abi_version() == 3
     return True
 
 

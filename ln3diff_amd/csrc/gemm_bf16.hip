@@ -33,6 +33,7 @@ struct GemmP {
   void* out0; void* out1; void* out2;
   const float* gate; int gate_rows; int64_t gate_ld;
   int tokens, tok_pad, heads, head_dim, transpose_mask, head_dim_pad;
+  int ctx_keys, ctx_pad; float ctx_scale_log2;
   int abl;   // bench-only ablation bits of the ring kernel (LN3D_GEMM_ABL): 1 = skip the epilogue, 2 = 2 K-stages only, 4 = no DMA in steady state
 };
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
   if constexpr (EPI == LN3D_EPI_F32) {
     *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb) = make_float4(v0, v1, v2, v3);
   } else if constexpr (EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH ||
-                       EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU) {
+                       EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU || EPI == LN3D_EPI_CROSS_ATTN) {
     if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
     if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
     if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
@@ -409,6 +410,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP
   bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
   const int ns = (p.abl & 2) ? 2 : p.K / 64;
 
+  // CROSS_ATTN: the K rows of this tile's sample and 4 heads go into the LDS above the ring now (40 KB at 77 keys), long
+  // before the epilogue needs them.  Row r of head hh at XK + hh*XKH + r*128, 16-byte chunk c at c ^ ((r >> 1) & 7).
+  constexpr int XK = 2 * STAGEB, XKH = 96 * 128;
+  if constexpr (EPI == LN3D_EPI_CROSS_ATTN) {
+    static_assert(NI == 2 && NJ == 3 && WGT == 2 && NW == 8, "one head (64 features) per wave row, 256x192 tile");
+    const int bsmp = t0 / p.tokens;
+    const int nrows8 = (p.ctx_keys + 7) >> 3;                      // DMA instructions (8 rows each) per head
+    const bf16_t* kc = (const bf16_t*)p.out1 + ((int64_t)bsmp * p.heads + (f0 >> 6)) * p.ctx_pad * 64;
+    for (int idx = wid; idx < 4 * nrows8; idx += NW) {
+      const int hh = idx / nrows8, j = idx - hh * nrows8;
+      const int r = 8 * j + (lane >> 3);
+      const bf16_t* src_k = kc + ((int64_t)hh * p.ctx_pad + r) * 64 + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src_k, (lds_void_t*)(smem + XK + hh * XKH + j * 1024), 16, 0, 0);
+    }
+  }
+
 #pragma unroll
   for (int q = 0; q < NPW; ++q) Y_ISSUE1(0, q);
   if (ns > 1) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) Y_ISSUE1(1, q); }
@@ -461,6 +478,105 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP
   Y_STAGE(s, false, false);
 
   if ((p.abl & 1) && acc[0][0][0] != 12345.f) return;
+  if constexpr (EPI == LN3D_EPI_CROSS_ATTN) {
+    // acc[i][j] = q^T of head (f0/64 + wf): features (rows) x the wave's 96 tokens (columns, lane & 31 within block j).
+    // Same swapped products and lane-local softmax as csrc/attention.hip; q is consumed straight from the accumulators
+    // (bf16-rounded like the stored q of the unfused path): the B operand of k-step s is accumulator half s of feature
+    // block s/2, whose row order inside a 16-group is [0-3, 8-11, 4-7, 12-15] - the order the K cache stores its dims in.
+    const int bsmp = t0 / p.tokens;
+    const int nkb = (p.ctx_keys + 63) >> 6, nkt = (p.ctx_keys + 31) >> 5;
+    __builtin_amdgcn_s_barrier();                     // ring retired: V^T tiles of the 4 heads go to its start
+    {
+      const bf16_t* vc = (const bf16_t*)p.out2 + ((int64_t)bsmp * p.heads + (f0 >> 6)) * 64 * p.ctx_pad;
+      for (int idx = wid; idx < 4 * nkb * 8; idx += NW) {         // (head, key block, 8 pieces of 8 rows)
+        const int hh = idx / (nkb * 8), rem = idx - hh * nkb * 8, kb = rem >> 3, j = rem & 7;
+        const int vrow = 8 * j + (lane >> 3);
+        const bf16_t* src_v = vc + ((int64_t)hh * 64 + vrow) * p.ctx_pad + kb * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src_v, (lds_void_t*)(smem + (hh * 2 + kb) * 8192 + j * 1024), 16, 0, 0);
+      }
+    }
+    const int kkey = (l31 >> 1) & 7;
+    const char* kbase = smem + XK + wf * XKH + l31 * 128;
+    float inv[NJ];
+    uint32_t pk[NJ][24];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x16 st[3];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        union { uint32_t u[4]; bf16x8 v; } qb;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          qb.u[jj] = pack2bf(acc[sd >> 1][j][8 * (sd & 1) + 2 * jj], acc[sd >> 1][j][8 * (sd & 1) + 2 * jj + 1]);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if (kt < nkt) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + kt * 32 * 128 + (((2 * sd + hi) ^ kkey) << 4));
+            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb.v, st[kt], 0, 0, 0);
+          }
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+          st[kt][r] = key < p.ctx_keys ? st[kt][r] : -3.0e38f;
+          mx = fmaxf(mx, st[kt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m = mx * p.ctx_scale_log2;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], p.ctx_scale_log2, -m));
+          st[kt][r] = pv;
+          psum += pv;
+        }
+      inv[j] = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+      // P (bf16 pairs) parks in the accumulator registers of token block j, which are dead now: key step ks of 16 keys ->
+      // 4 dwords at acc[ks >> 2][j][4 * (ks & 3) ...]
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          pk[j][4 * ks + jj] = pack2bf(st[ks >> 1][8 * (ks & 1) + 2 * jj], st[ks >> 1][8 * (ks & 1) + 2 * jj + 1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's V^T pieces landed
+    __builtin_amdgcn_s_barrier();                      // ... and everybody else's
+    const char* vbase = smem + (wf * 2) * 8192 + l31 * 128;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x16 oa[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[dt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks)
+        if (ks < 2 * nkt) {
+          union { uint32_t u[4]; bf16x8 v; } pb;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) pb.u[jj] = pk[j][4 * ks + jj];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vbase + (ks >> 2) * 8192 + dt * 32 * 128 + (((2 * (ks & 3) + hi) ^ kkey) << 4));
+            oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb.v, oa[dt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][j][r] = oa[dt][r] * inv[j];
+    }
+    // acc now holds O^T of the head in the accumulator layout of a plain GEMM tile: the staged epilogue writes it as bf16
+  }
   bool direct = false;
   if constexpr (EPI == LN3D_EPI_HEADS) direct = (p.transpose_mask != 0) && (f0 + BF > 2 * p.heads * p.head_dim);
   if (direct) {
@@ -486,8 +602,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP
 
 template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
-  constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT, LDSB = 2 * (BF + BT) * 128;
-  static_assert(LDSB >= NW * 8192, "staging regions live in the ring");
+  constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
+  constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? 4 * 96 * 128 : 0);
+  static_assert(2 * (BF + BT) * 128 >= NW * 8192 && LDSB <= 163840, "staging regions live in the ring");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>),
@@ -515,6 +632,8 @@ static int launch(const GemmP& p, hipStream_t s) {
 // cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (all 8 waves, LDS-DMA ring)
 template <int EPI>
 static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
+  if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
+  else
   switch (cfg) {
     case 7: return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
     case 8: return launch_ring64<EPI, 8, 4, 2, 3>(p, s);
@@ -568,6 +687,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.tokens = a->tokens; p.tok_pad = a->tok_pad; p.heads = a->heads; p.head_dim = a->head_dim;
   p.transpose_mask = a->transpose_mask;
   p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
+  p.ctx_keys = a->ctx_keys; p.ctx_pad = a->ctx_pad; p.ctx_scale_log2 = a->ctx_scale * 1.4426950408889634f;
   { const char* e = getenv("LN3D_GEMM_ABL"); p.abl = e ? atoi(e) : 0; }
   hipStream_t s = (hipStream_t)stream;
   const int cfg = pick_cfg(a->M, a->N);
@@ -578,6 +698,12 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
     case LN3D_EPI_GELU_TANH: return run_cfg<LN3D_EPI_GELU_TANH>(p, s, cfg);
     case LN3D_EPI_SILU: return run_cfg<LN3D_EPI_SILU>(p, s, cfg);
     case LN3D_EPI_QUICK_GELU: return run_cfg<LN3D_EPI_QUICK_GELU>(p, s, cfg);
+    case LN3D_EPI_CROSS_ATTN:
+      if (!a->out1 || !a->out2 || a->bias || a->head_dim != 64 || a->heads <= 0 || a->N != a->heads * 64 || a->tokens <= 0 ||
+          (a->tokens % 192) != 0 || (a->M % a->tokens) != 0 || a->ctx_keys <= 0 || a->ctx_keys > 96 || a->ctx_pad < a->ctx_keys ||
+          (a->ctx_pad % 64) != 0 || (a->N % 256) != 0)
+        return LN3D_ERR_BAD_ARG;
+      return run_cfg<LN3D_EPI_CROSS_ATTN>(p, s, 9);
     case LN3D_EPI_GATE_RES: return run_cfg<LN3D_EPI_GATE_RES>(p, s, cfg);
     case LN3D_EPI_F32_SILU:
       if (!a->out1) return LN3D_ERR_BAD_ARG;

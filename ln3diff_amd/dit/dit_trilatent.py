@@ -15,6 +15,8 @@ returning float32 [B, C*3, H, W]); the forward pass is a fixed sequence of HIP l
   final       : LN+modulate+Linear(D->p*p*C)+unpatchify in one kernel.
 The residual stream, LN statistics, softmax and all accumulators are fp32; GEMM operands are bf16.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -175,7 +177,10 @@ class DiT_TriLatent(DiT):
         for i, q in enumerate(P['blocks']):
             ops.gemm(cp, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad,
                      heads=H, head_dim=dh, transpose_mask=0b10)
-        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn}
+        # K copy whose 64 head dims are stored in the 16-group order [0-3, 8-11, 4-7, 12-15]: the order in which the query
+        # projection's accumulators hand q to the MFMA when cross-attention runs inside that GEMM (LN3D_EPI_CROSS_ATTN)
+        kp_all = k_all[..., ops.vt_key_order(dh, dev)].contiguous()
+        return {'k': k_all, 'kp': kp_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn}
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -244,6 +249,8 @@ class DiT_TriLatent(DiT):
         oc = ws.get('oc', (M, H * 64), torch.bfloat16)
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
 
+        fused_cross = (N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
+                       and not os.environ.get('LN3D_NO_FUSED_CROSS'))
         for i, q in enumerate(P['blocks']):
             o6 = i * 6 * D
             sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
@@ -252,8 +259,12 @@ class DiT_TriLatent(DiT):
             ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
             ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=nmod)
             # cross attention on x (no pre-norm, no gate; reference :318)
-            ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
-            ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
+            if fused_cross:     # q projection + attention over the cached text context in ONE kernel (q stays in registers)
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_CROSS_ATTN, oc, cc['kp'][i], cc['vt'][i], M=M, tokens=N, heads=H,
+                         head_dim=64, ctx_keys=cc['Lc'], ctx_pad=cc['lpad'], ctx_scale=64 ** -0.5)
+            else:
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
+                ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
             ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
             ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=nmod)
             ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES,  # noqa: F401
-                   EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU)
+                   EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU, EPI_CROSS_ATTN)
 
 
 def _p(t):
@@ -24,7 +24,8 @@ def _chk_dev(*ts):
 
 
 def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, gate=None, gate_rows=1,
-         gate_ld=0, tokens=0, tok_pad=0, heads=0, head_dim=0, transpose_mask=0, head_dim_pad=0):
+         gate_ld=0, tokens=0, tok_pad=0, heads=0, head_dim=0, transpose_mask=0, head_dim_pad=0, ctx_keys=0, ctx_pad=0,
+         ctx_scale=0.0):
     """out = epi(x[M,K] @ w[N,K]^T + bias).  x, w bf16 (row stride = shape[-1])."""
     _chk_dev(x, w, out0)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -40,6 +41,7 @@ def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, 
     a.gate, a.gate_rows, a.gate_ld = _p(gate), gate_rows, gate_ld
     a.tokens, a.tok_pad, a.heads, a.head_dim, a.transpose_mask = tokens, tok_pad, heads, head_dim, transpose_mask
     a.head_dim_pad = head_dim_pad
+    a.ctx_keys, a.ctx_pad, a.ctx_scale = ctx_keys, ctx_pad, float(ctx_scale)
     L.check(L.lib().ln3d_gemm_bf16(C.byref(a), _stream()), "gemm")
 
 

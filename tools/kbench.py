@@ -88,3 +88,14 @@ if os.environ.get('KBENCH_VENDOR', '1') == '1':
         w = (torch.randn(N_, K_, device=dev) * 0.03).to(torch.bfloat16)
         us = timeit(lambda: torch.matmul(a, w.t()))
         print(f'{nm:34s} M{M_} N{N_} K{K_}: {us:8.1f} us  {2.0 * M_ * N_ * K_ / us / 1e6:7.1f} TF/s')
+
+# fused query projection + cross-attention (LN3D_EPI_CROSS_ATTN) vs the two separate kernels above
+Lc, lpad = 77, 128
+xq = torch.randn(M, 1024, device=dev).to(torch.bfloat16)
+wq = (torch.randn(1024, 1024, device=dev) * 0.03).to(torch.bfloat16)
+kcx = torch.zeros(16, 16, lpad, 64, device=dev, dtype=torch.bfloat16); kcx[:, :, :Lc] = torch.randn(16, 16, Lc, 64, device=dev).to(torch.bfloat16)
+vtx = torch.randn(16, 16, 64, lpad, device=dev).to(torch.bfloat16)
+oc = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
+us = timeit(lambda: ops.gemm(xq, wq, None, ops.EPI_CROSS_ATTN, oc, kcx, vtx, M=M, tokens=768, heads=16, head_dim=64, ctx_keys=Lc,
+                             ctx_pad=lpad, ctx_scale=0.125))
+print(f'to_q + cross-attn fused (CROSS_ATTN epilogue)              : {us:8.1f} us')
