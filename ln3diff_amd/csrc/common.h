@@ -61,6 +61,28 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// two elements at a time: the polynomial / scaling parts become v_pk_mul_f32 / v_pk_fma_f32 (one instruction per pair);
+// same A&S 7.1.26 evaluation order per element as gelu_erf
+typedef float ln3d_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
+  const ln3d_f32x2 x = {x0, x1};
+  const ln3d_f32x2 z = x * 0.70710678118654752f;
+  const ln3d_f32x2 az = {fabsf(z.x), fabsf(z.y)};
+  const ln3d_f32x2 d = __builtin_elementwise_fma(az, ln3d_f32x2{0.3275911f, 0.3275911f}, ln3d_f32x2{1.0f, 1.0f});
+  const ln3d_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  ln3d_f32x2 p = {1.061405429f, 1.061405429f};
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{0.254829592f, 0.254829592f});
+  const ln3d_f32x2 w = az * az * -1.4426950408889634f;                 // exp(-z^2) = exp2(-z^2 log2 e)
+  const ln3d_f32x2 ex = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const ln3d_f32x2 pt = p * t * ex;
+  const ln3d_f32x2 e = ln3d_f32x2{1.0f, 1.0f} - pt;
+  const ln3d_f32x2 es = {copysignf(e.x, z.x), copysignf(e.y, z.y)};
+  const ln3d_f32x2 r = __builtin_elementwise_fma(es, x * 0.5f, x * 0.5f);
+  x0 = r.x; x1 = r.y;
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));

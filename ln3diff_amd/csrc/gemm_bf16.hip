@@ -271,12 +271,15 @@ struct RunEpi {
         uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
         *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)(tb + row) * p.ldo + fb) = o;
       }
+    } else if constexpr (EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU) {
+      uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);     // bias + activation were applied before staging
+      *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + fb) = o;
     } else {
       float v0 = v.x + bias.x, v1 = v.y + bias.y, v2 = v.z + bias.z, v3 = v.w + bias.w;
       const int64_t off = (int64_t)(tb + row) * p.ldo + fb;
       if constexpr (EPI == LN3D_EPI_F32 || EPI == LN3D_EPI_F32_SILU)
         *reinterpret_cast<float4*>((float*)p.out0 + off) = make_float4(v0, v1, v2, v3);
-      if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+      if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
       if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
       if constexpr (EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_F32_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
       if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
@@ -291,6 +294,7 @@ struct RunEpi {
 template <int EPI, int NI, int NJ>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
   static_assert(NI % 2 == 0, "feature blocks are staged in pairs");
+  constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rrow = lane >> 4, rc = lane & 15;
 #pragma unroll
@@ -300,6 +304,16 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
     RunEpi<EPI> re;
     int which = 0, h = 0, d = 0;
     if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
+    float4 pre_bias[2][4];
+    if constexpr (kPreAct) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fa = fw0 + ih * 64 + ii * 32 + 8 * g + 4 * hi;      // the accumulator quad's features
+          pre_bias[ii][g] = (p.bias && fa < p.N) ? *reinterpret_cast<const float4*>(p.bias + fa) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int tb = __builtin_amdgcn_readfirstlane(tw0 + j * 32);
@@ -309,9 +323,19 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = ii * 8 + 2 * g + hi;
-          *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
-              make_float4(acc[2 * ih + ii][j][4 * g + 0], acc[2 * ih + ii][j][4 * g + 1], acc[2 * ih + ii][j][4 * g + 2],
-                          acc[2 * ih + ii][j][4 * g + 3]);
+          float v0 = acc[2 * ih + ii][j][4 * g + 0], v1 = acc[2 * ih + ii][j][4 * g + 1], v2 = acc[2 * ih + ii][j][4 * g + 2],
+                v3 = acc[2 * ih + ii][j][4 * g + 3];
+          if constexpr (kPreAct) {
+            // bias + activation here, on the accumulator quads (all independent: full ILP), not on the read-back side
+            // where every lane walks a dependent chain per row
+            const float4 b = pre_bias[ii][g];
+            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+            if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+            if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+            if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+            if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
+          }
+          *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) = make_float4(v0, v1, v2, v3);
         }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
