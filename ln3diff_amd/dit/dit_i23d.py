@@ -35,6 +35,10 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         self.attention_y_norm = RMSNormP(1024)
         self.pooling_ctx_dim = pooling_ctx_dim
 
+    def _append_proj(self):
+        """CaptionEmbedder whose output tokens are appended to the self-attention sequence."""
+        return self.dino_proj
+
     def _ensure_packed(self, device):
         if self._packed is not None and self._packed['device'] == device:
             return
@@ -50,7 +54,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P['cap_ln_w'], P['cap_ln_b'] = f32(self.cap_embedder[0].weight, device), f32(self.cap_embedder[0].bias, device)
         P['cap_w'], P['cap_b'] = bf16(self.cap_embedder[1].weight, device), f32(self.cap_embedder[1].bias, device)
         P['ynorm_w'] = f32(self.attention_y_norm.weight, device)
-        dp = self.dino_proj.y_proj
+        dp = self._append_proj().y_proj
         P['d_w1'], P['d_b1'] = bf16(dp.fc1.weight, device), f32(dp.fc1.bias, device)
         P['d_w2'], P['d_b2'] = bf16(dp.fc2.weight, device), f32(dp.fc2.bias, device)
         P['sst'] = f32(torch.stack([b.scale_shift_table.reshape(-1) for b in self.blocks], 0), device)   # [depth, 6D]
@@ -75,6 +79,42 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         self._packed = P
         self._ws = Workspace(device)
 
+    def _cls_token(self, vec):
+        """pooled token: LayerNorm(affine, eps 1e-5) -> Linear   (dit_i23d.py:211-217,245)"""
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        Bn = vec.shape[0]
+        vn = ws.get('cap_vn', (Bn, self.pooling_ctx_dim), torch.bfloat16)
+        ops.norm_modulate(vec.contiguous().float(), vn, Bn, self.pooling_ctx_dim, kind=0, eps=1e-5, weight=P['cap_ln_w'],
+                          shift=P['cap_ln_b'], scale=P['zeros'], mod_rows=1 << 30, mod_ld=0)
+        cls = torch.empty(Bn, D, device=vec.device, dtype=torch.float32)
+        ops.gemm(vn, P['cap_w'], P['cap_b'], ops.EPI_F32, cls)
+        return cls
+
+    def _appended_tokens(self, feats):
+        """CaptionEmbedder (Linear -> tanh-GELU -> Linear) of [Bn, L, C] features -> bf16 [Bn, L, D]."""
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        Bn, L, C = feats.shape
+        fin = ws.get('app_in', (Bn * L, C), torch.bfloat16)
+        ops.cast_bf16(feats.contiguous().float(), fin)
+        h1 = ws.get('app_h', (Bn * L, D), torch.bfloat16)
+        ops.gemm(fin, P['d_w1'], P['d_b1'], ops.EPI_GELU_TANH, h1)
+        out = torch.empty(Bn, L, D, device=feats.device, dtype=torch.bfloat16)
+        ops.gemm(h1, P['d_w2'], P['d_b2'], ops.EPI_BF16, out)
+        return out
+
+    def _cross_kv(self, ctx_bf16, Bn, Lk):
+        """every block's cross-attention K (k_norm applied) / V^T of a [Bn*Lk, C] bf16 context."""
+        P, H = self._packed, self.num_heads
+        lpad = (Lk + 63) // 64 * 64
+        dev = ctx_bf16.device
+        k_all = torch.zeros(self.depth, Bn, H, lpad, 64, dtype=torch.bfloat16, device=dev)
+        vt_all = torch.zeros(self.depth, Bn, H, 64, lpad, dtype=torch.bfloat16, device=dev)
+        for i, q in enumerate(P['blocks']):
+            ops.gemm(ctx_bf16, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lk, tokens=Lk, tok_pad=lpad,
+                     heads=H, head_dim=64, transpose_mask=0b10)
+            ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
+        return k_all, vt_all, lpad
+
     @torch.no_grad()
     def prepare_context(self, context):
         ca, vec = context['crossattn'], context['vector']
@@ -83,12 +123,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P, ws = self._packed, self._ws
         Bn, Lc, _ = ca.shape
         D, H, C1 = self.embed_dim, self.num_heads, self.clip_ctx_dim
-        # pooled token: LayerNorm(affine, eps 1e-5) -> Linear   (dit_i23d.py:211-217,245)
-        vn = ws.get('cap_vn', (Bn, self.pooling_ctx_dim), torch.bfloat16)
-        ops.norm_modulate(vec.contiguous().float(), vn, Bn, self.pooling_ctx_dim, kind=0, eps=1e-5, weight=P['cap_ln_w'],
-                          shift=P['cap_ln_b'], scale=P['zeros'], mod_rows=1 << 30, mod_ld=0)
-        cls = torch.empty(Bn, D, device=dev, dtype=torch.float32)
-        ops.gemm(vn, P['cap_w'], P['cap_b'], ops.EPI_F32, cls)
+        cls = self._cls_token(vec)
         # CLIP tokens: RMSNorm once (dit_i23d.py:247); DINO tokens: tanh-GELU MLP
         clip_n = ws.get('clip_n', (Bn * Lc, C1), torch.bfloat16)
         ops.norm_modulate(ca[..., :C1].contiguous().float(), clip_n, Bn * Lc, C1, kind=1, eps=1e-5, weight=P['ynorm_w'])
@@ -179,6 +214,42 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         return eps
 
 
+class DiT_I23D_PixelArt_MVCond(DiT_I23D_PixelArt):
+    """Multi-view image conditioned variant (reference dit/dit_i23d.py:293-384): the projected CLIP spatial tokens
+    (clip_spatial_proj) are appended to the self-attention sequence, the flattened multi-view DINO features context['concat']
+    [B, V, L, C] are the cross-attention context (raw: no attention_y_norm, no projection); `dino_proj` does not exist.
+    Same blocks / kernels as the single-view model: only the prompt-side preparation differs."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        del self.dino_proj
+
+    def _append_proj(self):
+        return self.clip_spatial_proj
+
+    @torch.no_grad()
+    def prepare_context(self, context):
+        ca, vec, mv = context['crossattn'], context['vector'], context['concat']
+        self._ensure_packed(ca.device)
+        ws = self._ws
+        Bn = ca.shape[0]
+        cls = self._cls_token(vec)
+        appended = self._appended_tokens(ca)
+        Lk = mv.shape[1] * mv.shape[2]
+        mvb = ws.get('mv_in', (Bn * Lk, mv.shape[3]), torch.bfloat16)
+        ops.cast_bf16(mv.reshape(Bn * Lk, mv.shape[3]).contiguous().float(), mvb)
+        k_all, vt_all, lpad = self._cross_kv(mvb, Bn, Lk)
+        return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': appended}
+
+
+def DiT_L_Pixelart_MV_2(**kwargs):
+    return DiT_I23D_PixelArt_MVCond(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_B_Pixelart_MV_2(**kwargs):
+    return DiT_I23D_PixelArt_MVCond(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
+
+
 def DiT_L_Pixelart_2(**kwargs):
     return DiT_I23D_PixelArt(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
 
@@ -187,4 +258,7 @@ def DiT_B_Pixelart_2(**kwargs):
     return DiT_I23D_PixelArt(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
 
 
-DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2}
+DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
+              # reference registry (dit_i23d.py:686-696): 'DiT-PixArt-MV-B/2' is the MVCond class; its 'MV-L/2' entry points to the
+              # no-CLIP variant, which is not built here, so the CLIP+DINO L/2 is registered under an explicit name
+              'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2, 'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2}

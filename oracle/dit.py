@@ -225,6 +225,30 @@ def i23d_forward(sd, x, timesteps, context, num_heads, patch=2, clip_ctx_dim=102
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
 
+def i23d_mv_forward(sd, x, timesteps, context, num_heads, patch=2):
+    """DiT_I23D_PixelArt_MVCond.forward (dit/dit_i23d.py:293-384): multi-view image conditioning.  The projected CLIP spatial
+    tokens (clip_spatial_proj) are the ones appended to the self-attention sequence and the flattened multi-view DINO features
+    context['concat'] [B, V, L, C] are the cross-attention context, raw (no attention_y_norm, no projection); dino_proj is gone."""
+    B = x.shape[0]
+    depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    vec = context['vector'].float()
+    cls = F.linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
+                   sd['cap_embedder.1.weight'], sd['cap_embedder.1.bias'])
+    clip_tok = caption_embedder(sd, 'clip_spatial_proj.', context['crossattn'].float())
+    mv = context['concat'].float()
+    dino_tok = mv.reshape(B, mv.shape[1] * mv.shape[2], mv.shape[3])
+    t = t_embedder(sd, timesteps.float()) + cls
+    t0 = F.linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    h = patchify_embed(sd, x, patch) + sd['pos_embed']
+    for i in range(depth):
+        h = i23d_block(sd, f'blocks.{i}.', h, t0, clip_tok, dino_tok, num_heads)       # (appended, cross-attended)
+    shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
+    y = layer_norm(h) * (1 + scale) + shift
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    c_out = y.shape[-1] // (patch * patch)
+    return unpatchify_trilatent(y, B, patch, c_out).float()
+
+
 def i23d_forward_with_cfg(sd, x, t, context, cfg_scale, num_heads):
     eps = i23d_forward(sd, x, t, context, num_heads)
     cond, uncond = torch.split(eps, len(eps) // 2, dim=0)

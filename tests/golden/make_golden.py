@@ -257,6 +257,22 @@ def sec_i23d():
         check(f'flow {method} num_steps={steps} final latent', y_or, y_ref, 2e-4)
         save(f'flow_tiny_{method}{steps}', final=y_ref)
 
+    # multi-view conditioned variant (DiT_I23D_PixelArt_MVCond): CLIP spatial tokens appended, flattened MV DINO features cross-attended
+    from dit.dit_i23d import DiT_I23D_PixelArt_MVCond
+    with torch.no_grad():
+        mm = DiT_I23D_PixelArt_MVCond(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2,
+                                      num_classes=0, learn_sigma=False, context_dim=768, roll_out=True, pooling_ctx_dim=768).eval()
+    sdm, shapes_m = load_synth(mm, 0)
+    xm = synth_input('x', (2, 12, 32, 32), 5)
+    tm = torch.tensor([0.4, 0.7])
+    ctxm = {'crossattn': synth_input('ca', (2, 256, 1024), 5), 'vector': synth_input('v', (2, 768), 5),
+            'concat': synth_input('mv', (2, 4, 256, 768), 5)}
+    with torch.no_grad():
+        ym_ref = mm(xm, tm, ctxm)
+    ym_or = odit.i23d_mv_forward(sdm, xm, tm, ctxm, 2)
+    check('tiny I23D MVCond forward', ym_or, ym_ref)
+    save('i23d_mv_tiny', y=ym_ref, t=tm, manifest=manifest_json(shapes_m))
+
     # SDE samplers (transport.Sampler.sample_sde: Euler-Maruyama / Heun; noise from the global CPU generator)
     for method, steps, form, last in (('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'), ('Euler', 12, 'decreasing', 'Tweedie')):
         fn = Sampler(tr).sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=0.7, last_step=last,

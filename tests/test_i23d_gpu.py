@@ -114,3 +114,22 @@ def test_dopri5_converges_to_fixed_step_solution(hip_lib):
         errs.append(rel_l2(y[-1].cpu(), ref.cpu()))
         print('dopri5 rtol', rtol, 'rel-l2 vs heun-200', errs[-1], fn.last_stats)
     assert errs[-1] < 5e-3 and errs[-1] <= errs[0] * 1.5
+
+
+def test_i23d_multiview_variant_vs_reference_golden(hip_lib):
+    """DiT_I23D_PixelArt_MVCond (CLIP spatial tokens appended, flattened multi-view DINO features cross-attended, Nk = 1024)."""
+    from ln3diff_amd.dit.dit_i23d import DiT_I23D_PixelArt_MVCond
+    from ln3diff_amd.synth import synth_input
+    g = golden('i23d_mv_tiny')
+    m = DiT_I23D_PixelArt_MVCond(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=0,
+                                 learn_sigma=False, context_dim=768, roll_out=True, pooling_ctx_dim=768)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (2, 12, 32, 32), 5).cuda()
+    ctx = {'crossattn': synth_input('ca', (2, 256, 1024), 5).cuda(), 'vector': synth_input('v', (2, 768), 5).cuda(),
+           'concat': synth_input('mv', (2, 4, 256, 768), 5).cuda()}
+    y = m(x, torch.from_numpy(g['t']).cuda(), ctx).cpu()
+    e = rel_l2(y, g['y'])
+    print('i23d MVCond tiny', e)
+    assert e < 2e-2, e

@@ -172,3 +172,12 @@ def test_oracle_clip_text_matches_transformers_golden(name):
     sd = synth_state_dict(shapes, 0)
     last, pooled = oclip.clip_text_forward(sd, torch.from_numpy(g['ids']).long(), int(g['heads']), int(g['eos_token_id']))
     assert rel_l2(last, g['last']) < 1e-5 and rel_l2(pooled, g['pooled']) < 1e-5
+
+
+def test_oracle_i23d_multiview_matches_reference_golden():
+    g = golden('i23d_mv_tiny')
+    sd = _sd_from_manifest(g)
+    ctx = {'crossattn': synth_input('ca', (2, 256, 1024), 5), 'vector': synth_input('v', (2, 768), 5),
+           'concat': synth_input('mv', (2, 4, 256, 768), 5)}
+    y = odit.i23d_mv_forward(sd, synth_input('x', (2, 12, 32, 32), 5), torch.from_numpy(g['t']), ctx, 2)
+    assert rel_l2(y, g['y']) < 1e-4
