@@ -8,8 +8,8 @@
 //    row-sum are 32 in-register ops + one exchange with lane^32, the online-softmax rescale factor is a per-lane
 //    scalar, and P feeds the second MFMA directly as its B operand (no LDS round trip, no transposes): the key
 //    permutation of the accumulator layout is baked into the V^T memory layout (see attn_kernel).
-//  * softmax in the log2 domain: one FMA + one v_exp_f32 per score; the O rescale is skipped, wave-uniformly and
-//    exactly, when no row maximum moved.
+//  * softmax in the log2 domain: one FMA + one v_exp_f32 per score; the O rescale is deferred, wave-uniformly, until a
+//    row maximum outgrows the running reference by more than 2^8 (mathematically exact: softmax is shift-invariant).
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -145,8 +145,12 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);
-    if (!__all(m_new == m_run)) {
+    // Deferred rebase: the running reference m_run only has to bound the scores loosely (softmax is invariant to it), so
+    // O / l are rescaled - wave-uniformly - only when some row's block maximum outgrows it by more than 2^8; until then
+    // P = exp2(s - m_run) <= 256, well inside bf16 / fp32 range.  After the first blocks this branch is almost never taken.
+    const float m_blk = mx * p.scale_log2;
+    if (!__all(m_blk <= m_run + 8.0f)) {
+      const float m_new = fmaxf(m_run, m_blk);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float a = fmaf(st[kt][r], p.scale_log2, -m_new);
+        const float a = fmaf(st[kt][r], p.scale_log2, -m_run);
         const float pv = (LN3D_ATTN_ABL & 1) ? a : __builtin_amdgcn_exp2f(a);
         st[kt][r] = pv;
         psum += pv;
