@@ -249,6 +249,7 @@ class DiT_TriLatent(DiT):
         oc = ws.get('oc', (M, H * 64), torch.bfloat16)
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
 
+        probe = getattr(self, '_fc1_probe', None)
         fused_cross = (N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
                        and not os.environ.get('LN3D_NO_FUSED_CROSS'))
         for i, q in enumerate(P['blocks']):
@@ -267,7 +268,15 @@ class DiT_TriLatent(DiT):
                 ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
             ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
             ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=nmod)
-            ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+            if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
+                # measurement hook (bench.py): HIP events on the launch stream around this one GEMM, inside the real step
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+                e1.record()
+                probe['events'].append((e0, e1))
+            else:
+                ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=nmod)
 
         of = depth * 6 * D
