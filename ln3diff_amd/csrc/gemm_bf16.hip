@@ -293,8 +293,9 @@ struct RunEpi {
 
 template <int EPI, int NI, int NJ>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
-  static_assert(NI % 2 == 0, "feature blocks are staged in pairs");
   constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
+  constexpr bool kBf16Out = kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_CROSS_ATTN;
+  const bool wide = kBf16Out && (p.N & 7) == 0 && (p.ldo & 7) == 0;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rrow = lane >> 4, rc = lane & 15;
 #pragma unroll
@@ -304,6 +305,11 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
     RunEpi<EPI> re;
     int which = 0, h = 0, d = 0;
     if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
+    float4 wb0 = make_float4(0.f, 0.f, 0.f, 0.f), wb1 = wb0;
+    if (wide && !kPreAct && p.bias) {
+      const int f8 = fw0 + ih * 64 + 8 * (lane & 7);
+      if (f8 < p.N) { wb0 = *reinterpret_cast<const float4*>(p.bias + f8); wb1 = *reinterpret_cast<const float4*>(p.bias + f8 + 4); }
+    }
     float4 pre_bias[2][4];
     if constexpr (kPreAct) {
 #pragma unroll
@@ -337,10 +343,74 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
           }
           *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) = make_float4(v0, v1, v2, v3);
         }
+      if (wide) {
+        // bf16 outputs: 8 features (two staged chunks) per lane -> 16-byte stores, 8 lanes per 128-byte row segment; the
+        // 8-byte-per-lane form of the generic path costs ~15 % of a K = 1024 GEMM on this part
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const int f8 = fw0 + ih * 64 + 8 * c8;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = 4 * it + rrow;
-        const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+        for (int it = 0; it < 4; ++it) {
+          const int row = 8 * it + r8;
+          float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+          float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+          if constexpr (!kPreAct) {
+            v0.x += wb0.x; v0.y += wb0.y; v0.z += wb0.z; v0.w += wb0.w;
+            v1.x += wb1.x; v1.y += wb1.y; v1.z += wb1.z; v1.w += wb1.w;
+          }
+          uint4 o;
+          o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w); o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
+          if (tb + row < p.M && f8 < p.N) *reinterpret_cast<uint4*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + f8) = o;
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = 4 * it + rrow;
+          const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+          if (tb + row < p.M && fok) re.apply(p, tb, row, fb, v);
+        }
+      }
+    }
+  }
+  if constexpr (NI % 2 == 1) {
+    // last (odd) feature block alone: 32 tokens x 32 features, 128-byte staging rows, chunk c of row r at c ^ ((r >> 1) & 7);
+    // 8 lanes come back with the 32 consecutive features of one token
+    constexpr int i = NI - 1;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int fb = fw0 + i * 32 + 4 * c8;
+    const bool fok = fb < p.N;
+    RunEpi<EPI> re;
+    int which = 0, h = 0, d = 0;
+    if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
+    float4 pre_bias[4];
+    if constexpr (kPreAct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fa = fw0 + i * 32 + 8 * g + 4 * hi;
+        pre_bias[g] = (p.bias && fa < p.N) ? *reinterpret_cast<const float4*>(p.bias + fa) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int tb = __builtin_amdgcn_readfirstlane(tw0 + j * 32);
+      if (fok && tb < p.M) re.init(p, fb, tb, which, h, d);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 2 * g + hi;
+        float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+        if constexpr (kPreAct) {
+          const float4 b = pre_bias[g];
+          v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+          if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+          if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+          if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+          if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
+        }
+        *reinterpret_cast<float4*>(stg + l31 * 128 + ((c ^ ((l31 >> 1) & 7)) << 4)) = make_float4(v0, v1, v2, v3);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = 8 * it + r8;
+        const float4 v = *reinterpret_cast<const float4*>(stg + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
         if (tb + row < p.M && fok) re.apply(p, tb, row, fb, v);
       }
     }
@@ -602,7 +672,85 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP
     // acc now holds O^T of the head in the accumulator layout of a plain GEMM tile: the staged epilogue writes it as bf16
   }
   bool direct = false;
-  if constexpr (EPI == LN3D_EPI_HEADS) direct = (p.transpose_mask != 0) && (f0 + BF > 2 * p.heads * p.head_dim);
+  if constexpr (EPI == LN3D_EPI_HEADS) {
+    direct = (p.transpose_mask != 0) && (f0 + BF > 2 * p.heads * p.head_dim);
+    // A wave row that is exactly one head of a transposed target (V^T) goes through LDS transposed: each store instruction
+    // then writes 16 rows x 64 contiguous bytes of V^T instead of 64 scattered 2-byte elements.
+    if constexpr (NI == 2) {
+      const int dm = p.heads * p.head_dim;
+      if (p.head_dim == 64 && p.head_dim_pad == 64 && (p.tokens & 31) == 0 && (p.M % p.tokens) == 0 && (p.N % 64) == 0) {
+        const int fw0 = f0 + wf * 64;
+        const int which = fw0 / dm;                                   // wave-uniform
+        const bool tr = fw0 < p.N && ((p.transpose_mask >> which) & 1);
+        __builtin_amdgcn_s_barrier();                                 // ring retired (all waves take this branch)
+        if (tr) {
+          char* stg = smem + wid * 8192;
+          const int h = (fw0 - which * dm) >> 6;
+          bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+          const int fr = lane >> 2, c = lane & 3;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int tb = __builtin_amdgcn_readfirstlane(t0 + wt * 32 * NJ + j * 32);
+            if (tb >= p.M) break;
+            const int tp = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);     // key order of the attention kernel
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  *reinterpret_cast<float*>(stg + (i * 32 + 8 * g + 4 * hi + e) * 128 + tp * 4) = acc[i][j][4 * g + e];
+            const int b = tb / p.tokens, t = tb - b * p.tokens;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int f = 16 * it + fr;
+              const float bv = p.bias ? p.bias[fw0 + f] : 0.f;
+              const float4 v0 = *reinterpret_cast<const float4*>(stg + f * 128 + c * 32);
+              const float4 v1 = *reinterpret_cast<const float4*>(stg + f * 128 + c * 32 + 16);
+              uint4 o;
+              o.x = pack2bf(v0.x + bv, v0.y + bv); o.y = pack2bf(v0.z + bv, v0.w + bv);
+              o.z = pack2bf(v1.x + bv, v1.y + bv); o.w = pack2bf(v1.z + bv, v1.w + bv);
+              *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * 64 + f) * p.tok_pad + t + 8 * c) = o;
+            }
+          }
+        } else if (fw0 < p.N) {
+          // q / k: [B, heads, tok_pad, 64] - the wave's 32 tokens x 64 features of one head are 4 KB of CONTIGUOUS memory:
+          // stage as usual (row = token), come back with 8 features per lane and store 16 bytes per lane, 1 KB per instruction
+          char* stg = smem + wid * 8192;
+          const int h = (fw0 - which * dm) >> 6;
+          bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+          const int r8 = lane >> 3, c8 = lane & 7;
+          float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+          if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8); b1 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8 + 4); }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int tb = __builtin_amdgcn_readfirstlane(t0 + wt * 32 * NJ + j * 32);
+            if (tb >= p.M) break;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int c = i * 8 + 2 * g + hi;
+                *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
+                    make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+              }
+            const int b = tb / p.tokens, t = tb - b * p.tokens;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = 8 * it + r8;
+              const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+              const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+              uint4 o;
+              o.x = pack2bf(v0.x + b0.x, v0.y + b0.y); o.y = pack2bf(v0.z + b0.z, v0.w + b0.w);
+              o.z = pack2bf(v1.x + b1.x, v1.y + b1.y); o.w = pack2bf(v1.z + b1.z, v1.w + b1.w);
+              *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * p.tok_pad + t + row) * 64 + 8 * c8) = o;
+            }
+          }
+        }
+        return;
+      }
+    }
+  }
   if (direct) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -653,7 +801,8 @@ static int launch(const GemmP& p, hipStream_t s) {
   return ln3d_check_launch();
 }
 
-// cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (all 8 waves, LDS-DMA ring)
+// cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (8 waves), 12 = 384f x 192t (12 waves,
+// 3 per SIMD), 11 = 384f x 192t with 8 waves (96x96 wave tiles; kept for A/B runs)
 template <int EPI>
 static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
@@ -662,6 +811,8 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
     case 7: return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
     case 8: return launch_ring64<EPI, 8, 4, 2, 3>(p, s);
     case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
+    case 11: return launch_ring64<EPI, 8, 2, 3, 3>(p, s);
+    case 12: return launch_ring64<EPI, 12, 2, 2, 3>(p, s);
     default: return launch<EPI>(p, s);
   }
 }
@@ -681,16 +832,17 @@ static int num_cus() {
 // kernel.  Otherwise the ring configuration with the least estimated time: rounds of one tile per CU x tile area / relative
 // throughput of the tile shape (measured at K = 1024 on MI355X: 256x256 1.00, 256x192 0.95, 128x384 0.945 - the L2 -> LDS
 // fill is the limiter, so throughput follows the tile's flop/byte).  DiT-L/2 at 12288 tokens: N = 4096 -> 256x256 (3 full
-// rounds), N = 1024 / 3072 -> 256x192 (1 / 3 full rounds).
+// rounds), N = 3072 -> 384x192 with 12 waves (2 full rounds), N = 1024 -> 256x192 (1 full round).
 static int pick_cfg(int M, int N) {
   const char* force = getenv("LN3D_GEMM_TILE");
   if (force && force[0] == 's') return 0;
   if (force && force[0] == 'x') return atoi(force + 1);
   if (!(M >= 1536 && N >= 128)) return 0;
-  static const struct { int cfg, bf, bt; float speed; } C[3] = {{7, 256, 256, 1.0f}, {9, 256, 192, 0.95f}, {8, 128, 384, 0.945f}};
+  static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
+                                                               {8, 128, 384, 0.945f}};
   const int cus = num_cus();
   int best = 8; float best_cost = 1e30f;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int64_t tiles = (int64_t)((N + C[i].bf - 1) / C[i].bf) * ((M + C[i].bt - 1) / C[i].bt);
     const float cost = (float)((tiles + cus - 1) / cus) * (float)(C[i].bf * C[i].bt) / C[i].speed;
     if (cost < best_cost) { best_cost = cost; best = C[i].cfg; }
