@@ -235,13 +235,15 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
               make_float4(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
         }
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = 4 * it + rrow;
-        const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+      for (int it = 0; it < 4; ++it) {               // 8 dims per lane: 16-byte stores, 8 lanes per 128-byte row
+        const int row = 8 * it + (lane >> 3), c8 = lane & 7;
+        const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+        const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
         const int q = q0 + row;
         if (q < p.Nq) {
-          uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + dp * 64 + 4 * rc) = o;
+          uint4 o;
+          o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w); o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
+          *reinterpret_cast<uint4*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + dp * 64 + 8 * c8) = o;
         }
       }
     }
