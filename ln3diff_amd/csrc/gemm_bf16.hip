@@ -4,17 +4,20 @@
 //  * MFMA v_mfma_f32_32x32x16_bf16, 64-lane wavefronts.  The MFMA "A" operand is the WEIGHT tile
 //    (rows = output features) and the "B" operand the TOKEN tile, so the fp32 accumulator fragment
 //    of a lane holds 4 consecutive output FEATURES of one token ( row = (r&3)+8(r>>2)+4(lane>>5),
-//    col = lane&31 ) -> every epilogue store is a contiguous 8-byte (bf16) / 16-byte (f32) piece of
-//    an output row, and per-feature bias / per-(sample,feature) gates are 4-wide vector loads.
-//  * Small-problem kernel: 128(features) x 128(tokens) x 64(K) block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles
+//    col = lane&31 ): per-feature bias / per-(sample,feature) gates are 4-wide vector loads, and the
+//    accumulators double as the B operand of a following product (LN3D_EPI_CROSS_ATTN).
+//  * Large problems: LDS-DMA ring kernels (gemm_bf16_ring64_kernel below: 256x256 / 384x192 / 256x192 / 128x384 tiles,
+//    K stages of 64 = full cache lines, epilogue through LDS with 16-byte stores).
+//  * Small problems: 128(features) x 128(tokens) x 64(K) block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles
 //    (64 accumulator VGPRs).  Both operands are K-contiguous in HBM ([rows, K] row-major), staged
 //    HBM -> VGPR (global_load_dwordx4, 8 lanes cover one 128-B row segment) -> LDS rows padded to
 //    144 B, which makes the ds_read_b128 fragment reads bank-conflict free (16 distinct rows of a
 //    b128 lane-group land on 16 distinct 16-B slots: 144*r mod 256).  Double-buffered LDS, the next
 //    tile's global loads are issued before the MFMA block of the current tile (latency hidden under
 //    16 MFMAs/wave), one barrier per K-tile.
-//  * Epilogues fused: bias, GELU(erf/tanh), SiLU, gate*out+residual (adaLN-zero gating into the fp32
-//    residual stream, optional bf16 copy), head split with V^T emission for the attention kernel.
+//  * Epilogues fused: bias, GELU(erf/tanh/quick), SiLU, gate*out+residual (adaLN-zero gating into the fp32
+//    residual stream, optional bf16 copy), head split with V^T emission for the attention kernel,
+//    cross-attention over a short cached context.
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/ln3d.h"
