@@ -103,6 +103,14 @@ int ln3d_embed_tokens(const int32_t* ids, const float* tok_emb, const float* pos
 /* affine LayerNorm f32 -> f32 (final_layer_norm; last_hidden_state / pooled stay fp32), D % 128 == 0, D <= 1152 */
 int ln3d_layernorm_f32(const float* x, const float* w, const float* b, float* y, int64_t rows, int D, float eps, void* stream);
 
+/* ---------------------------------------------------------------- image conditioner helpers (open_clip ViT-L/14 visual tower,
+ * DINOv2 ViT-L/14-reg: sgm/modules/encoders/modules.py:578-869)
+ * patchify: out bf16 [B*(S/p)^2, Kpad], column c*p*p + i*p + j = img[b, c, gy*p+i, gx*p+j], columns >= 3*p*p zero
+ * assemble: x f32 [B, 1+R+L, D]: cls + pos[0] ; R register tokens ; patch[b, n] + pos[1+n] */
+int ln3d_vit_patchify(const float* img, void* out_bf16, int B, int S, int p, int Kpad, void* stream);
+int ln3d_vit_assemble(const float* patch, const float* cls, const float* reg, const float* pos, float* x, int B, int L, int R, int D,
+                      void* stream);
+
 /* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
  * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40) */
 int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, float eps, void* stream);

@@ -256,6 +256,52 @@ extern "C" int ln3d_layernorm_f32(const float* x, const float* w, const float* b
   return ln3d_check_launch();
 }
 
+// ------------------------------------------------------------------ image conditioner helpers (ViT towers)
+// out[(b*G + gy)*G + gx, c*p*p + i*p + j] = bf16(img[b, c, gy*p + i, gx*p + j]), columns >= 3*p*p zero (K padded to a
+// multiple of 64 for the GEMM): the patch-embedding convolution (kernel = stride = p) becomes one GEMM
+__global__ void vit_patchify_kernel(const float* img, bf16_t* out, int B, int S, int p, int Kpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = S / p, KK = 3 * p * p;
+  const int64_t total = (int64_t)B * G * G * Kpad;
+  if (i >= total) return;
+  const int k = (int)(i % Kpad);
+  const int64_t row = i / Kpad;
+  float v = 0.f;
+  if (k < KK) {
+    const int c = k / (p * p), ij = k - c * p * p, ii = ij / p, jj = ij - ii * p;
+    const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((int64_t)G * G));
+    v = img[(((int64_t)b * 3 + c) * S + gy * p + ii) * S + gx * p + jj];
+  }
+  out[i] = f2bf(v);
+}
+extern "C" int ln3d_vit_patchify(const float* img, void* out, int B, int S, int p, int Kpad, void* stream) {
+  if (!img || !out || B <= 0 || S <= 0 || p <= 0 || S % p || Kpad < 3 * p * p) return LN3D_ERR_BAD_ARG;
+  const int64_t total = (int64_t)B * (S / p) * (S / p) * Kpad;
+  hipLaunchKernelGGL(vit_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, S, p, Kpad);
+  return ln3d_check_launch();
+}
+// x[b, 0] = cls + pos[0]; x[b, 1..R] = reg; x[b, 1+R+n] = patch[b, n] + pos[1+n]   (f32, T = 1 + R + L tokens)
+__global__ void vit_assemble_kernel(const float* patch, const float* cls, const float* reg, const float* pos, float* x, int B, int L,
+                                    int R, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = 1 + R + L;
+  if (i >= (int64_t)B * T * D) return;
+  const int d = (int)(i % D);
+  const int t = (int)((i / D) % T), b = (int)(i / ((int64_t)D * T));
+  float v;
+  if (t == 0) v = cls[d] + pos[d];
+  else if (t <= R) v = reg[(int64_t)(t - 1) * D + d];
+  else { const int n = t - 1 - R; v = patch[((int64_t)b * L + n) * D + d] + pos[(int64_t)(1 + n) * D + d]; }
+  x[i] = v;
+}
+extern "C" int ln3d_vit_assemble(const float* patch, const float* cls, const float* reg, const float* pos, float* x, int B, int L, int R,
+                                 int D, void* stream) {
+  if (!patch || !cls || !pos || !x || (R > 0 && !reg) || B <= 0 || L <= 0 || R < 0 || D <= 0) return LN3D_ERR_BAD_ARG;
+  const int64_t total = (int64_t)B * (1 + R + L) * D;
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, patch, cls, reg, pos, x, B, L, R, D);
+  return ln3d_check_launch();
+}
+
 // ------------------------------------------------------------------ small elementwise
 __global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -204,3 +204,11 @@ def embed_tokens(ids, tok_emb, pos_emb, out, B, T, D):
 
 def layernorm_f32(x, w, b, y, rows, D, eps=1e-5):
     L.check(L.lib().ln3d_layernorm_f32(_p(x), _p(w), _p(b), _p(y), C.c_int64(rows), D, C.c_float(eps), _stream()), "layernorm_f32")
+
+
+def vit_patchify(img, out, B, S, p, Kpad):
+    L.check(L.lib().ln3d_vit_patchify(_p(img), _p(out), B, S, p, Kpad, _stream()), "vit_patchify")
+
+
+def vit_assemble(patch, cls, reg, pos, x, B, Lp, R, D):
+    L.check(L.lib().ln3d_vit_assemble(_p(patch), _p(cls), _p(reg), _p(pos), _p(x), B, Lp, R, D, _stream()), "vit_assemble")

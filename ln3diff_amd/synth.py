@@ -96,3 +96,15 @@ def orbit_cameras(n_views, radius=1.7719, elevation_deg=15.0, focal=1.3889):
         K = torch.tensor([[focal, 0, 0.5], [0, focal, 0.5], [0, 0, 1.]])
         cams.append(torch.cat([c2w.reshape(-1), K.reshape(-1)]))
     return torch.stack(cams)
+
+
+def synth_vit_state_dict(shapes, seed=0):
+    """synth_state_dict for the image-conditioner towers: learned positional embeddings (0.02 * N) and LayerScale gammas
+    (1 + 0.1 * N, so that the scaled branches matter in parity tests) get their own rules."""
+    comp = {}
+    for k, shp in shapes.items():
+        if k.endswith('pos_embed'):
+            comp[k] = synth_input('w:' + k, shp, seed, 0.02)
+        elif k.endswith('.gamma'):
+            comp[k] = 1.0 + synth_input('w:' + k, shp, seed, 0.1)
+    return synth_state_dict(shapes, seed, comp)

@@ -1,0 +1,75 @@
+"""CPU restatement (TEST INFRASTRUCTURE ONLY - see oracle/__init__.py) of the image conditioners on the I23D path.
+
+sgm.modules.encoders.modules.FrozenOpenCLIPImageEmbedder (/root/reference/sgm/modules/encoders/modules.py:578-733, arch
+ViT-L-14 'openai', output_tokens=True) wraps open_clip's VisionTransformer and FrozenDinov2ImageEmbedder (:735-869) wraps the
+torch.hub DINOv2 ViT-L/14 with registers; both packages are third-party and absent from the reference tree AND from this image,
+so the algorithms are restated from their published definitions with the packages' own state-dict key layouts, and the
+arithmetic is pinned against the architecture-identical HuggingFace models that ARE installed here
+(CLIPVisionModelWithProjection / Dinov2WithRegistersModel, tests/golden/make_golden_vit.py).  Key naming and the kornia
+bicubic+antialias resize of `preprocess` stay unpinned (inputs here are already 224x224 and normalised).
+
+open_clip VisionTransformer (output_tokens=True, final_ln_after_pool=False): conv1 (no bias) -> [class_embedding ; patches] +
+positional_embedding -> ln_pre -> resblocks (pre-LN, fused in_proj, quick-GELU for the 'openai' weights) -> ln_post on ALL
+tokens -> pooled = x[:, 0] @ proj, tokens = x[:, 1:].
+DINOv2 (forward_features, is_training=True): patch_embed (bias) ; [cls ; patches] + pos_embed ; registers inserted after cls
+-> blocks (pre-LN, fused qkv, LayerScale ls1/ls2, erf-GELU) -> norm -> x_norm_clstoken = x[:, 0], x_norm_patchtokens =
+x[:, 1 + R:].
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _attn(x, w_qkv, b_qkv, w_o, b_o, heads):
+    B, T, D = x.shape
+    q, k, v = F.linear(x, w_qkv, b_qkv).chunk(3, -1)
+    q, k, v = (t.reshape(B, T, heads, D // heads).transpose(1, 2) for t in (q, k, v))
+    a = torch.softmax(q @ k.transpose(-1, -2) * (D // heads) ** -0.5, -1) @ v
+    return F.linear(a.transpose(1, 2).reshape(B, T, D), w_o, b_o)
+
+
+def _patches(img, w, b, p):
+    x = F.conv2d(img, w, b, stride=p)                 # [B, D, G, G]
+    return x.flatten(2).transpose(1, 2)               # [B, G*G, D]
+
+
+def openclip_visual_forward(sd, img, heads, patch=14, eps=1e-5, prefix='visual.'):
+    g = lambda k: sd[prefix + k].float()
+    x = _patches(img.float(), g('conv1.weight'), None, patch)
+    B, _, D = x.shape
+    x = torch.cat([g('class_embedding').expand(B, 1, D), x], 1) + g('positional_embedding')[None]
+    x = F.layer_norm(x, (D,), g('ln_pre.weight'), g('ln_pre.bias'), eps)
+    n = 1 + max(int(k[len(prefix):].split('.')[2]) for k in sd if k.startswith(prefix + 'transformer.resblocks.'))
+    for i in range(n):
+        L = f'transformer.resblocks.{i}.'
+        h = F.layer_norm(x, (D,), g(L + 'ln_1.weight'), g(L + 'ln_1.bias'), eps)
+        x = x + _attn(h, g(L + 'attn.in_proj_weight'), g(L + 'attn.in_proj_bias'), g(L + 'attn.out_proj.weight'),
+                      g(L + 'attn.out_proj.bias'), heads)
+        h = F.layer_norm(x, (D,), g(L + 'ln_2.weight'), g(L + 'ln_2.bias'), eps)
+        h = F.linear(h, g(L + 'mlp.c_fc.weight'), g(L + 'mlp.c_fc.bias'))
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + F.linear(h, g(L + 'mlp.c_proj.weight'), g(L + 'mlp.c_proj.bias'))
+    pre_ln = x
+    x = F.layer_norm(x, (D,), g('ln_post.weight'), g('ln_post.bias'), eps)
+    pooled = x[:, 0] @ g('proj')
+    return pooled, x[:, 1:], pre_ln
+
+
+def dinov2_forward(sd, img, heads, patch=14, eps=1e-6):
+    g = lambda k: sd[k].float()
+    x = _patches(img.float(), g('patch_embed.proj.weight'), g('patch_embed.proj.bias'), patch)
+    B, _, D = x.shape
+    x = torch.cat([g('cls_token').expand(B, 1, D), x], 1) + g('pos_embed')
+    R = sd['register_tokens'].shape[1] if 'register_tokens' in sd else 0
+    if R:
+        x = torch.cat([x[:, :1], g('register_tokens').expand(B, R, D), x[:, 1:]], 1)
+    n = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    for i in range(n):
+        L = f'blocks.{i}.'
+        h = F.layer_norm(x, (D,), g(L + 'norm1.weight'), g(L + 'norm1.bias'), eps)
+        x = x + g(L + 'ls1.gamma') * _attn(h, g(L + 'attn.qkv.weight'), g(L + 'attn.qkv.bias'), g(L + 'attn.proj.weight'),
+                                            g(L + 'attn.proj.bias'), heads)
+        h = F.layer_norm(x, (D,), g(L + 'norm2.weight'), g(L + 'norm2.bias'), eps)
+        h = F.gelu(F.linear(h, g(L + 'mlp.fc1.weight'), g(L + 'mlp.fc1.bias')))
+        x = x + g(L + 'ls2.gamma') * F.linear(h, g(L + 'mlp.fc2.weight'), g(L + 'mlp.fc2.bias'))
+    x = F.layer_norm(x, (D,), g('norm.weight'), g('norm.bias'), eps)
+    return x[:, 0], x[:, 1 + R:]

@@ -181,3 +181,17 @@ def test_oracle_i23d_multiview_matches_reference_golden():
            'concat': synth_input('mv', (2, 4, 256, 768), 5)}
     y = odit.i23d_mv_forward(sd, synth_input('x', (2, 12, 32, 32), 5), torch.from_numpy(g['t']), ctx, 2)
     assert rel_l2(y, g['y']) < 1e-4
+
+
+def test_oracle_image_towers_match_transformers_goldens():
+    import json
+    from oracle import vit_image as ovit
+    from ln3diff_amd.synth import synth_vit_state_dict
+    g = golden('vit_clip_tiny')
+    sh = {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
+    pooled, tokens, _ = ovit.openclip_visual_forward(synth_state_dict(sh, 0), synth_input('img', (2, 3, 56, 56), 3), int(g['heads']))
+    assert rel_l2(pooled, g['pooled']) < 1e-5 and rel_l2(tokens[:, ::int(g['tok_stride'])], g['tokens']) < 1e-5
+    g = golden('vit_dino_tiny')
+    sh = {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
+    cls, tokens = ovit.dinov2_forward(synth_vit_state_dict(sh, 0), synth_input('img', (2, 3, 56, 56), 4), int(g['heads']))
+    assert rel_l2(cls, g['cls']) < 1e-5 and rel_l2(tokens[:, ::int(g['tok_stride'])], g['tokens']) < 1e-5

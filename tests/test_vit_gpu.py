@@ -1,0 +1,66 @@
+"""Image conditioners (open_clip ViT-L/14 visual tower, DINOv2 ViT-L/14-reg) on the HIP kernels vs goldens produced by the
+architecture-identical `transformers` models in the build container (tests/golden/make_golden_vit.py)."""
+import json
+
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+from ln3diff_amd.synth import synth_input, synth_state_dict, synth_vit_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _shapes(g):
+    return {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 2), ("vitl14", 1)])
+def test_openclip_visual_tower_vs_golden(hip_lib, name, B):
+    from ln3diff_amd.sgm.image_encoders import FrozenOpenCLIPImageEmbedder
+    g = golden(f'vit_clip_{name}')
+    sh = _shapes(g)
+    D, I = sh['visual.transformer.resblocks.0.mlp.c_fc.weight'][1], sh['visual.transformer.resblocks.0.mlp.c_fc.weight'][0]
+    n = 1 + max(int(k.split('.')[3]) for k in sh if '.resblocks.' in k)
+    S = int(g['size'])
+    m = FrozenOpenCLIPImageEmbedder(output_tokens=True, width=D, mlp_width=I, layers=n, heads=int(g['heads']), image_size=S,
+                                    embed_dim=sh['visual.proj'][1], arch="ViT-L-14" if D == 1024 else "custom")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {'model.' + k: v for k, v in sh.items()}
+    m.load_state_dict({'model.' + k: v for k, v in synth_state_dict(sh, 0).items()}, strict=True)
+    img = synth_input('img', (B, 3, S, S), 3).cuda()          # the golden fed this tensor to the tower directly
+    m.preprocess = lambda x: x
+    tokens, pooled = m(img)
+    st = int(g['tok_stride'])
+    e1 = rel_l2(pooled.cpu(), g['pooled'])
+    e2 = rel_l2(tokens[:, ::st].cpu(), torch.from_numpy(g['tokens']).float())
+    print('openclip visual', name, e1, e2)
+    assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 2), ("vitl14reg", 1)])
+def test_dinov2_tower_vs_golden(hip_lib, name, B):
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder
+    g = golden(f'vit_dino_{name}')
+    sh = _shapes(g)
+    D = sh['cls_token'][-1]
+    n = 1 + max(int(k.split('.')[1]) for k in sh if k.startswith('blocks.'))
+    S = int(g['size'])
+    m = FrozenDinov2ImageEmbedder(output_cls=True, width=D, layers=n, heads=int(g['heads']), image_size=S,
+                                  num_register_tokens=sh['register_tokens'][1])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {'model.' + k: v for k, v in sh.items()}
+    m.load_state_dict({'model.' + k: v for k, v in synth_vit_state_dict(sh, 0).items()}, strict=True)
+    img = synth_input('img', (B, 3, S, S), 4).cuda()
+    m.preprocess = lambda x: x
+    cls, tokens = m(img)
+    st = int(g['tok_stride'])
+    e1 = rel_l2(cls.cpu(), g['cls'])
+    e2 = rel_l2(tokens[:, ::st].cpu(), torch.from_numpy(g['tokens']).float())
+    print('dinov2', name, e1, e2)
+    assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
+
+
+def test_image_embedder_rejects_unresized_input(hip_lib):
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder
+    m = FrozenDinov2ImageEmbedder(width=128, layers=1, heads=2, image_size=56)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64, device='cuda'))
