@@ -51,12 +51,15 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P['t_w0'], P['t_b0'] = bf16(self.t_embedder.mlp[0].weight, device), f32(self.t_embedder.mlp[0].bias, device)
         P['t_w2'], P['t_b2'] = bf16(self.t_embedder.mlp[2].weight, device), f32(self.t_embedder.mlp[2].bias, device)
         P['ada_w'], P['ada_b'] = bf16(self.adaLN_modulation[1].weight, device), f32(self.adaLN_modulation[1].bias, device)
-        P['cap_ln_w'], P['cap_ln_b'] = f32(self.cap_embedder[0].weight, device), f32(self.cap_embedder[0].bias, device)
-        P['cap_w'], P['cap_b'] = bf16(self.cap_embedder[1].weight, device), f32(self.cap_embedder[1].bias, device)
-        P['ynorm_w'] = f32(self.attention_y_norm.weight, device)
-        dp = self._append_proj().y_proj
-        P['d_w1'], P['d_b1'] = bf16(dp.fc1.weight, device), f32(dp.fc1.bias, device)
-        P['d_w2'], P['d_b2'] = bf16(dp.fc2.weight, device), f32(dp.fc2.bias, device)
+        if hasattr(self, 'cap_embedder'):
+            P['cap_ln_w'], P['cap_ln_b'] = f32(self.cap_embedder[0].weight, device), f32(self.cap_embedder[0].bias, device)
+            P['cap_w'], P['cap_b'] = bf16(self.cap_embedder[1].weight, device), f32(self.cap_embedder[1].bias, device)
+        if hasattr(self, 'attention_y_norm'):
+            P['ynorm_w'] = f32(self.attention_y_norm.weight, device)
+        if self._append_proj() is not None:
+            dp = self._append_proj().y_proj
+            P['d_w1'], P['d_b1'] = bf16(dp.fc1.weight, device), f32(dp.fc1.bias, device)
+            P['d_w2'], P['d_b2'] = bf16(dp.fc2.weight, device), f32(dp.fc2.bias, device)
         P['sst'] = f32(torch.stack([b.scale_shift_table.reshape(-1) for b in self.blocks], 0), device)   # [depth, 6D]
         blks = []
         for b in self.blocks:
@@ -242,6 +245,38 @@ class DiT_I23D_PixelArt_MVCond(DiT_I23D_PixelArt):
         return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': appended}
 
 
+class DiT_I23D_PixelArt_MVCond_noClip(DiT_I23D_PixelArt):
+    """Multi-view variant without any CLIP branch (reference dit/dit_i23d.py:387-492; registered there as
+    'DiT-PixArt-MV-L/2'): t = t_embedder(timesteps), nothing is appended to the self-attention sequence
+    (ImageCondDiTBlockPixelArtNoclip), cross-attention over the flattened multi-view DINO features context['concat'];
+    dino_proj, clip_spatial_proj and cap_embedder do not exist."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        del self.dino_proj
+        del self.clip_spatial_proj, self.cap_embedder
+
+    def _append_proj(self):
+        return None
+
+    @torch.no_grad()
+    def prepare_context(self, context):
+        mv = context['concat']
+        dev = mv.device
+        self._ensure_packed(dev)
+        Bn, D = mv.shape[0], self.embed_dim
+        Lk = mv.shape[1] * mv.shape[2]
+        mvb = self._ws.get('mv_in', (Bn * Lk, mv.shape[3]), torch.bfloat16)
+        ops.cast_bf16(mv.reshape(Bn * Lk, mv.shape[3]).contiguous().float(), mvb)
+        k_all, vt_all, lpad = self._cross_kv(mvb, Bn, Lk)
+        return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': torch.zeros(Bn, D, device=dev),
+                'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
+
+
+def DiT_L_Pixelart_MV_2_noclip(**kwargs):
+    return DiT_I23D_PixelArt_MVCond_noClip(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
 def DiT_L_Pixelart_MV_2(**kwargs):
     return DiT_I23D_PixelArt_MVCond(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
 
@@ -259,6 +294,6 @@ def DiT_B_Pixelart_2(**kwargs):
 
 
 DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
-              # reference registry (dit_i23d.py:686-696): 'DiT-PixArt-MV-B/2' is the MVCond class; its 'MV-L/2' entry points to the
-              # no-CLIP variant, which is not built here, so the CLIP+DINO L/2 is registered under an explicit name
-              'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2, 'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2}
+              # reference registry (dit_i23d.py:686-696): 'MV-L/2' is the no-CLIP class, 'MV-B/2' the CLIP+DINO one
+              'DiT-PixArt-MV-L/2': DiT_L_Pixelart_MV_2_noclip, 'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2,
+              'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2}

@@ -249,6 +249,28 @@ def i23d_mv_forward(sd, x, timesteps, context, num_heads, patch=2):
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
 
+def i23d_mv_noclip_forward(sd, x, timesteps, context, num_heads, patch=2):
+    """DiT_I23D_PixelArt_MVCond_noClip.forward (dit/dit_i23d.py:387-492, the class the reference registers as
+    'DiT-PixArt-MV-L/2'): no CLIP branch at all - t = t_embedder(timesteps), nothing is appended to the self-attention
+    sequence (ImageCondDiTBlockPixelArtNoclip, dit_models_xformers.py:540-596), cross-attention over the flattened
+    multi-view DINO features."""
+    B = x.shape[0]
+    depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    mv = context['concat'].float()
+    dino_tok = mv.reshape(B, mv.shape[1] * mv.shape[2], mv.shape[3])
+    t = t_embedder(sd, timesteps.float())
+    t0 = F.linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    h = patchify_embed(sd, x, patch) + sd['pos_embed']
+    none = h.new_zeros(B, 0, h.shape[-1])
+    for i in range(depth):
+        h = i23d_block(sd, f'blocks.{i}.', h, t0, none, dino_tok, num_heads)
+    shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
+    y = layer_norm(h) * (1 + scale) + shift
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    c_out = y.shape[-1] // (patch * patch)
+    return unpatchify_trilatent(y, B, patch, c_out).float()
+
+
 def i23d_forward_with_cfg(sd, x, t, context, cfg_scale, num_heads):
     eps = i23d_forward(sd, x, t, context, num_heads)
     cond, uncond = torch.split(eps, len(eps) // 2, dim=0)

@@ -273,6 +273,17 @@ def sec_i23d():
     check('tiny I23D MVCond forward', ym_or, ym_ref)
     save('i23d_mv_tiny', y=ym_ref, t=tm, manifest=manifest_json(shapes_m))
 
+    from dit.dit_i23d import DiT_I23D_PixelArt_MVCond_noClip          # what the registry calls 'DiT-PixArt-MV-L/2'
+    with torch.no_grad():
+        mn = DiT_I23D_PixelArt_MVCond_noClip(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2,
+                                             num_classes=0, learn_sigma=False, context_dim=768, roll_out=True, pooling_ctx_dim=768).eval()
+    sdn, shapes_n = load_synth(mn, 0)
+    with torch.no_grad():
+        yn_ref = mn(xm, tm, {'concat': ctxm['concat']})
+    yn_or = odit.i23d_mv_noclip_forward(sdn, xm, tm, ctxm, 2)
+    check('tiny I23D MVCond_noClip forward', yn_or, yn_ref)
+    save('i23d_mv_noclip_tiny', y=yn_ref, t=tm, manifest=manifest_json(shapes_n))
+
     # SDE samplers (transport.Sampler.sample_sde: Euler-Maruyama / Heun; noise from the global CPU generator)
     for method, steps, form, last in (('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'), ('Euler', 12, 'decreasing', 'Tweedie')):
         fn = Sampler(tr).sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=0.7, last_step=last,

@@ -133,3 +133,21 @@ def test_i23d_multiview_variant_vs_reference_golden(hip_lib):
     e = rel_l2(y, g['y'])
     print('i23d MVCond tiny', e)
     assert e < 2e-2, e
+
+
+def test_i23d_multiview_noclip_variant_vs_reference_golden(hip_lib):
+    """DiT_I23D_PixelArt_MVCond_noClip (the registry's 'DiT-PixArt-MV-L/2'): no CLIP branch, nothing appended, Nk = 1024."""
+    from ln3diff_amd.dit.dit_i23d import DiT_I23D_PixelArt_MVCond_noClip, DiT_models
+    from ln3diff_amd.synth import synth_input
+    assert DiT_models['DiT-PixArt-MV-L/2'].__name__ == 'DiT_L_Pixelart_MV_2_noclip'
+    g = golden('i23d_mv_noclip_tiny')
+    m = DiT_I23D_PixelArt_MVCond_noClip(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2,
+                                        num_classes=0, learn_sigma=False, context_dim=768, roll_out=True, pooling_ctx_dim=768)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (2, 12, 32, 32), 5).cuda()
+    y = m(x, torch.from_numpy(g['t']).cuda(), {'concat': synth_input('mv', (2, 4, 256, 768), 5).cuda()}).cpu()
+    e = rel_l2(y, g['y'])
+    print('i23d MVCond_noClip tiny', e)
+    assert e < 2e-2, e

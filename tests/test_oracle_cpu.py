@@ -195,3 +195,11 @@ def test_oracle_image_towers_match_transformers_goldens():
     sh = {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
     cls, tokens = ovit.dinov2_forward(synth_vit_state_dict(sh, 0), synth_input('img', (2, 3, 56, 56), 4), int(g['heads']))
     assert rel_l2(cls, g['cls']) < 1e-5 and rel_l2(tokens[:, ::int(g['tok_stride'])], g['tokens']) < 1e-5
+
+
+def test_oracle_i23d_multiview_noclip_matches_reference_golden():
+    g = golden('i23d_mv_noclip_tiny')
+    sd = _sd_from_manifest(g)
+    y = odit.i23d_mv_noclip_forward(sd, synth_input('x', (2, 12, 32, 32), 5), torch.from_numpy(g['t']),
+                                    {'concat': synth_input('mv', (2, 4, 256, 768), 5)}, 2)
+    assert rel_l2(y, g['y']) < 1e-4
