@@ -21,6 +21,7 @@ struct AttnP {
   int64_t ldo;
   float scale_log2;
   int causal;
+  int nsplit;   // attn_stream_kernel: workgroups per (batch, head)
 };
 
 #define KVB 64
@@ -43,6 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef LN3D_ATTN_ABL
 #define LN3D_ATTN_ABL 0
 #endif
+
 
 template <int DH, int OCC>
 __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
@@ -251,6 +253,352 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming kernel for the DiT self-attention shapes: Dh = 64, Nk a multiple of 256 (768 / 1024 latent tokens, the 256-token
+// planes of the VAE decoder).
+//
+// What bounds attention on this part is INSTRUCTION ISSUE, not the matrix pipe: a SIMD issues about one instruction per 4-5
+// cycles whatever its wave count (profiles/r2_attn_pmc.md: attn_kernel above and the first versions of this kernel all ran
+// at 5.5-6.5 cycles per issued instruction per SIMD; removing every MFMA changed nothing, removing any other instruction
+// class helped in proportion to its count).  A v_mfma_f32_32x32x16_bf16 occupies the pipe for 32 cycles, so the matrix pipe
+// is only kept busy if there are <= ~7 other instructions per MFMA.  attn_kernel issues ~15 (200 VALU per 16 MFMAs plus
+// address / counter / branch overhead).  This kernel is written against that budget:
+//  * softmax VALU per score: ONE v_exp_f32, half a v_pk_add_f32, half a v_cvt_pk_bf16_f32, half a v_max3_f32.  The scale
+//    is folded into the query fragment once per query block (q * scale * log2 e) and the running reference -m is the C
+//    operand of the first S^T MFMA of every tile (a persistent 16-register broadcast), so the accumulators ARE
+//    s*scale*log2e - m: no multiply-add per score.  The row-maximum test of the deferred rebase needs no cross-lane
+//    exchange (the wave-wide vote covers both half-rows).
+//  * no address arithmetic in the loop: the step loop is unrolled over the 4 ring slots, every ds_read_b128 is one of four
+//    lane-constant offset registers plus an immediate, the DMA source is a scalar base plus a lane-constant offset.
+//  * fragments are read one half-step ahead into a second register set; every wait in steady state is a counted one.
+//  * ONE workgroup (8 waves x 32 queries, 2 waves per SIMD, <= 256 VGPRs) walks ALL query blocks of its (batch, head) - or a
+//    contiguous share of them when there are fewer heads than CUs - while the K / V^T ring keeps streaming across
+//    query-block boundaries: one prologue per workgroup, the K / V^T re-reads of a head stay in the L2 of the XCD that owns
+//    it, and the step loop is software-pipelined across tiles (the S^T MFMAs of the next 32-key tile are issued under the
+//    exp2 / sum / pack work of the current one, whose PV MFMAs run under the row-maximum test of the next).
+//  * O leaves through a wave-private staging region beside the ring (the ring never retires here); the next query block's
+//    queries arrive in the same region by LDS-DMA one step ahead.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
+  constexpr int DH = 64, NDS = 4, NDT = 2;
+  constexpr int NST = 8;                                  // ring slots: 6 stages (96 KB) in flight per CU cover the L2 / MALL latency
+  constexpr int KTILE = 8192, STAGEB = 16384, RING = NST * STAGEB, QB = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // work item: (head, share of its query blocks).  Block b runs on XCD b % 8: the shares of a head stay on one XCD.
+  const int nqb = (p.Nq + QB - 1) / QB;
+  const int BH = p.B * p.H;
+  int bh, sp;
+  {
+    const int b = blockIdx.x;
+    if ((BH & 7) == 0) { const int xcd = b & 7, slot = b >> 3; bh = (slot / p.nsplit) * 8 + xcd; sp = slot % p.nsplit; }
+    else { bh = b / p.nsplit; sp = b % p.nsplit; }
+  }
+  const int qper = (nqb + p.nsplit - 1) / p.nsplit;
+  const int qb0 = sp * qper, qb1 = min(nqb, qb0 + qper);
+  if (qb0 >= qb1) return;
+  const int nkb = p.Nk >> 6;                              // key blocks of 64: a multiple of 4 (launcher)
+
+  const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
+  const char* Kg = reinterpret_cast<const char*>(p.K + (int64_t)bh * p.Nk_pad * DH);
+  const char* Vg = reinterpret_cast<const char*>(p.Vt + (int64_t)bh * DH * p.Nk_pad);
+  const int b_smp = bh / p.H, h_idx = bh - b_smp * p.H;
+
+  // Tile image shared by K rows, V^T rows and the wave's own Q rows: 128-byte rows, 16-byte chunk c of row r at
+  // c ^ ((r >> 1) & 7).  fo[j] = LDS ADDRESS of chunk 2j + hi of row l31 - the lane's fragment of contraction step j - in the
+  // ring half the current steps consume, fo_hi[j] the same in the other half (DS instructions carry 16-bit immediates: the
+  // two sets swap every 4 steps instead of adding a slot base per read).
+  typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t fo[4], fo_hi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { fo[j] = lds0 + l31 * 128 + (((2 * j + hi) ^ ((l31 >> 1) & 7)) << 4); fo_hi[j] = fo[j] + 65536; }
+  // DMA: wave w fills rows 8w..8w+7 of the K tile and of the V^T tile of a stage (1 KB each)
+  const int drow = 8 * wid + (lane >> 3), dchunk = ((lane & 7) ^ ((drow >> 1) & 7)) << 4;
+  const uint32_t koffs = drow * 128 + dchunk;
+  const uint32_t voffs = (uint32_t)drow * (uint32_t)p.Nk_pad * 2u + dchunk;
+  const char* kq = Kg; const char* vq = Vg;               // scalar: source of the next stage to issue
+  int kb_issue = 0;
+  int half_base = 0;                                      // LDS byte offset of the ring half (4 slots) the current steps consume
+  auto issue_stage = [&](auto slot_tag) __attribute__((always_inline)) {   // slot relative to the current half: 0..7
+    constexpr int SL = decltype(slot_tag)::value & (NST - 1);
+    char* dst = smem + ((SL >= 4 ? half_base ^ 65536 : half_base) + (SL & 3) * STAGEB + wid * 1024);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs), (lds_void_t*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs), (lds_void_t*)(dst + KTILE), 16, 0, 0);
+    ++kb_issue; kq += 64 * DH * 2; vq += 64 * 2;          // the stream wraps around the head's keys at every query block
+    if (kb_issue == nkb) { kb_issue = 0; kq = Kg; vq = Vg; }
+  };
+  // Queries of a query block: the wave's 32 rows x 128 B are contiguous in HBM and go through the wave's own 4 KB staging
+  // region by LDS-DMA, issued at the first step of the previous query block: no VGPRs are held for them.
+  bf16x8 qf[NDS];
+  char* const wstage = smem + RING + wid * 4096;
+  auto dma_q = [&](int qb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      int qr = qb * QB + wid * 32 + row; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), (lds_void_t*)(wstage + j * 1024), 16, 0, 0);
+    }
+  };
+  // (the caller has waited for the DMA)  fragments, scaled by scale * log2(e) and rounded to bf16 once more
+  auto read_q = [&]() __attribute__((always_inline)) {
+    const uint32_t qrow = lds0 + RING + wid * 4096 + l31 * 128;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      union { uint32_t u[4]; bf16x8 v; } cv;
+      cv.v = *(lds_frag_t*)(uintptr_t)(qrow + (((2 * ds + hi) ^ ((l31 >> 1) & 7)) << 4));
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        cv.u[jj] = pack2bf(bf2f((bf16_t)(cv.u[jj] & 0xffffu)) * p.scale_log2, bf2f((bf16_t)(cv.u[jj] >> 16)) * p.scale_log2);
+      qf[ds] = cv.v;
+    }
+  };
+
+  f32x16 oacc[NDT], negm, stA, stB;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float l_run = 0.f;
+
+  // Fragment registers.  All LDS reads of a half-step are issued at its top: the V^T columns of the current tile (multiplied
+  // in its last third) and the K rows of the tile AFTER next into the other of two K sets (used by the S^T MFMAs that open the
+  // next half-step), so no MFMA ever waits on a read that was just issued.  Addresses are fo[j] / fo_hi[j] + an immediate.
+  bf16x8 kfA[NDS], kfB[NDS], vf[2 * NDT];
+  auto load_kf = [&](bf16x8 (&kf)[NDS], auto slot_tag, auto kt_tag) __attribute__((always_inline)) {   // K rows of tile kt of a slot
+    constexpr int SL = decltype(slot_tag)::value;           // 0..3 in the current half, 4 = slot 0 of the other half
+    constexpr int OFF = (SL & 3) * STAGEB + decltype(kt_tag)::value * 4096;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) kf[ds] = *(lds_frag_t*)(uintptr_t)((SL >= 4 ? fo_hi[ds] : fo[ds]) + OFF);
+  };
+  auto load_vf = [&](bf16x8 (&vf)[2 * NDT], auto slot_tag, auto kt_tag) __attribute__((always_inline)) {   // V^T of the tile's 32 keys
+    constexpr int SL = decltype(slot_tag)::value;
+    constexpr int OFF = (SL & 3) * STAGEB + KTILE;
+    constexpr int KT = decltype(kt_tag)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        vf[s * NDT + dt] = *(lds_frag_t*)(uintptr_t)((SL >= 4 ? fo_hi[2 * KT + s] : fo[2 * KT + s]) + OFF + dt * 4096);
+  };
+  // S^T of a 32-key tile from its K fragments, C operand = cinit (0 for the first tile of a query block)
+  auto qk_tile = [&](f32x16& st, const bf16x8 (&kf)[NDS], const f32x16& cinit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      if constexpr (LN3D_ATTN_ABL & 2) { if (ds == 0) st = cinit; asm volatile("" :: "v"(kf[ds])); } else
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], ds == 0 ? cinit : st, 0, 0, 0);
+    }
+  };
+  auto tile_max = [&](const f32x16& st) __attribute__((always_inline)) {
+    float mx = max3f(st[0], st[1], st[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = max3f(mx, st[r], st[r + 1]);
+    return max3f(mx, st[15], st[15]);
+  };
+  // first tile of a query block: the reference becomes its row maximum (the accumulators hold s*scale*log2e, C was 0)
+  auto fresh_reference = [&](f32x16& st) __attribute__((always_inline)) {
+    float mx = tile_max(st);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -mx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] -= mx;
+  };
+  // O: bf16 through the wave's 4 KB (8-byte chunk c of row r at c ^ (r & 15)), out as 16 bytes per lane = whole 128-byte rows
+  auto store_o = [&](int qb) __attribute__((always_inline)) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q0 = qb * QB + wid * 32;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        uint2 o;
+        o.x = pack2bf(oacc[dt][4 * gq + 0] * inv, oacc[dt][4 * gq + 1] * inv);
+        o.y = pack2bf(oacc[dt][4 * gq + 2] * inv, oacc[dt][4 * gq + 3] * inv);
+        const int c8 = dt * 8 + 2 * gq + hi;
+        *reinterpret_cast<uint2*>(wstage + l31 * 128 + ((c8 ^ (l31 & 15)) << 3)) = o;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + (lane >> 3), c16 = lane & 7;
+      // chunks 2*c16 and 2*c16+1 of row r sit in one aligned 16-byte slot, swapped when r is odd
+      uint4 v = *reinterpret_cast<const uint4*>(wstage + r * 128 + ((c16 ^ ((r & 15) >> 1)) << 4));
+      if (r & 1) { const uint32_t t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+      const int q = q0 + r;
+      if (q < p.Nq) *reinterpret_cast<uint4*>(p.O + ((int64_t)b_smp * p.Nq + q) * p.ldo + h_idx * DH + c16 * 8) = v;
+    }
+  };
+
+  // One pipelined half-step: P and PV of the 32-key tile `cur`, while the S^T MFMAs of the NEXT tile (whose K rows are in kf)
+  // run into `nxt`; `loads` reads the V^T columns of the current tile and the K rows of the tile after next.
+  // MODE 0: next tile with C = -m ; 2: next tile opens the NEXT query block (C = 0, qf already holds its queries) ;
+  //      3: nothing follows.
+  // The reference m is only re-based when it has to be: P = exp2(s - m) is summed first and the wave votes on the SUM (a sum
+  // below 2^40 bounds every term; an overflowed exp2 makes it inf), so the common path carries no row-maximum at all.  bf16 and
+  // fp32 keep their relative precision over that range, and softmax is invariant to the reference.
+  auto half_step = [&](f32x16& cur, f32x16& nxt, auto mode_tag, const bf16x8 (&kf)[NDS], auto&& loads) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    if constexpr (!(LN3D_ATTN_ABL & 32)) loads();
+    if constexpr (MODE == 0) qk_tile(nxt, kf, negm);
+    if constexpr (MODE == 2) { f32x16 z; _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f; qk_tile(nxt, kf, z); }
+    f32x2 e[8];
+    f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      e[jj].x = (LN3D_ATTN_ABL & 1) ? cur[2 * jj] : __builtin_amdgcn_exp2f(cur[2 * jj]);
+      e[jj].y = (LN3D_ATTN_ABL & 1) ? cur[2 * jj + 1] : __builtin_amdgcn_exp2f(cur[2 * jj + 1]);
+      if (jj & 1) psb += e[jj]; else psa += e[jj];
+    }
+    psa += psb;
+    float tot = psa.x + psa.y;
+    if constexpr (!(LN3D_ATTN_ABL & 8)) {
+      if (!__all(tot <= 1.0e12f)) {
+        // rare (the first tiles of a query block, outlier keys): move the reference up to this tile's row maximum and redo its P
+        float mx = tile_max(cur);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] -= delta;
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nxt[r] -= delta;   // computed against the old reference
+        }
+        tot = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          e[jj].x = __builtin_amdgcn_exp2f(cur[2 * jj] - delta);
+          e[jj].y = __builtin_amdgcn_exp2f(cur[2 * jj + 1] - delta);
+          tot += e[jj].x + e[jj].y;
+        }
+      }
+    }
+    l_run += tot;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      union { uint32_t u[4]; bf16x8 v; } cv;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) cv.u[jj] = pack2bf(e[4 * s + jj].x, e[4 * s + jj].y);
+      pb[s] = cv.v;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        if constexpr (LN3D_ATTN_ABL & 2) { asm volatile("" :: "v"(vf[s * NDT + dt]), "v"(pb[s])); } else
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s * NDT + dt], pb[s], oacc[dt], 0, 0, 0);
+      }
+  };
+
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // ---- prologue: queries of the first block, 7 ring stages; stage 0 and the queries are the oldest 6 of the 18 requests
+  dma_q(qb0);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) {
+    // (constant slot per unrolled iteration)
+    switch (i) {
+      case 0: issue_stage(std::integral_constant<int, 0>{}); break; case 1: issue_stage(std::integral_constant<int, 1>{}); break;
+      case 2: issue_stage(std::integral_constant<int, 2>{}); break; case 3: issue_stage(std::integral_constant<int, 3>{}); break;
+      case 4: issue_stage(std::integral_constant<int, 4>{}); break; case 5: issue_stage(std::integral_constant<int, 5>{}); break;
+      default: issue_stage(std::integral_constant<int, 6>{}); break;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_q();
+  {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    load_kf(kfB, I0{}, I0{});
+    qk_tile(stA, kfB, z);
+    fresh_reference(stA);
+  }
+  load_kf(kfA, I0{}, I1{});
+
+  // ---- the stream.  Step g consumes the stage in slot g & 7: V^T of its key block, K of the next block from slot g+1.  At
+  // its top the stage in slot g+1 must have landed for everybody; the five stages behind it may stay in flight (10 requests,
+  // plus the 4 of a query DMA issued within the last 5 steps).  Behind the barrier every wave has left step g-1, whose slot is
+  // refilled with stage g+7.  A step = two half-steps with STATIC accumulator names: (stA -> stB) on tile 0, (stB -> stA) on
+  // tile 1.  The loop is unrolled over the 4 slots of a ring half (slot offsets are immediates); nkb is a multiple of 4, so a
+  // query block ends at the end of a half and the two address sets swap there.
+  if constexpr (LN3D_ATTN_ABL & 64) { store_o(qb0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }   // bench: prologue + one store only
+  // The wait is always "at most 10 requests outstanding": they are younger than stage g+1 whether or not the 4 requests of a
+  // query DMA (issued at the first step of a query block) are among them, and the queries are older than anything a boundary
+  // 6 or more steps later allows to be outstanding; only a 4-step query block (256 keys) has to ask for them by count.
+  auto top_of_step = [&](auto slot_tag, bool first, bool boundary, bool more, int qb) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if constexpr (!(LN3D_ATTN_ABL & 4)) {
+      if (boundary && nkb < 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (first && more) dma_q(qb + 1);
+    if constexpr (!(LN3D_ATTN_ABL & 16)) issue_stage(std::integral_constant<int, SL + 7>{});
+  };
+  auto swap_halves = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t t = fo[j]; fo[j] = fo_hi[j]; fo_hi[j] = t; }
+    half_base ^= 65536;
+  };
+  // half-step A (tile 0): S^T of tile 1 from kfA, reads V^T(tile 0) and K(next block, tile 0) -> kfB; half-step B the mirror
+#define HS_A(SL_, MODE_) half_step(stA, stB, MODE_{}, kfA, [&]() __attribute__((always_inline)) {                \
+    load_vf(vf, std::integral_constant<int, SL_>{}, I0{}); load_kf(kfB, std::integral_constant<int, SL_ + 1>{}, I0{}); })
+#define HS_B(SL_, MODE_) half_step(stB, stA, MODE_{}, kfB, [&]() __attribute__((always_inline)) {                \
+    load_vf(vf, std::integral_constant<int, SL_>{}, I1{}); if constexpr (MODE_::value != 3) load_kf(kfA, std::integral_constant<int, SL_ + 1>{}, I1{}); })
+#define STEP(SL_, FIRST_) { top_of_step(std::integral_constant<int, SL_>{}, FIRST_, false, more, qb); HS_A(SL_, I0); HS_B(SL_, I0); }
+  for (int qb = qb0; qb < qb1; ++qb) {
+    const bool more = qb + 1 < qb1;
+    bool first = true;
+    for (int grp = 4; grp < nkb; grp += 4) {
+      STEP(0, first); STEP(1, false); STEP(2, false); STEP(3, false);
+      swap_halves();
+      first = false;
+    }
+    STEP(0, first); STEP(1, false); STEP(2, false);
+    top_of_step(I3{}, false, more, more, qb);
+    HS_A(3, I0);
+    if (more) {
+      read_q();
+      HS_B(3, I2);
+      store_o(qb);
+      l_run = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+      fresh_reference(stA);
+      swap_halves();
+    } else {
+      HS_B(3, I3);
+      store_o(qb);
+    }
+  }
+#undef STEP
+#undef HS_A
+#undef HS_B
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ring's read-ahead must not outlive the workgroup's LDS
+}
+
+// ---------------------------------------------------------------------------------------------
 // Short key sequences (Nk <= 128: the 77-token text context of every cross-attention, the CLIP text tower), Dh = 64.
 // The general kernel above is latency-bound there (ring prologue, a barrier per block, 768 workgroups on 512 slots).  Here a
 // workgroup is 4 waves = 256 queries of one (batch, head), every wave takes two 32-query tiles in turn; K and V^T of the whole
@@ -452,6 +800,36 @@ static int launch_attn(const AttnP& p, hipStream_t s) {
   return ln3d_check_launch();
 }
 
+static int num_cus_attn() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+static int launch_attn_stream(AttnP p, hipStream_t s) {
+  constexpr int LDS = 8 * 16384 + 8 * 4096;     // all 160 KiB of the CU: one workgroup per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  // one workgroup per (batch, head) walks all its query blocks; with fewer heads than CUs the query blocks of a head are
+  // shared out so that every CU has work
+  const int nqb = (p.Nq + 255) / 256, BH = p.B * p.H, cus = num_cus_attn();
+  int nsplit = 1;
+  if (BH < cus) { nsplit = (cus + BH - 1) / BH; if (nsplit > nqb) nsplit = nqb; }
+  const char* fs = getenv("LN3D_ATTN_SPLIT");
+  if (fs) { nsplit = atoi(fs); if (nsplit < 1) nsplit = 1; if (nsplit > nqb) nsplit = nqb; }
+  p.nsplit = nsplit;
+  hipLaunchKernelGGL(attn_stream_kernel, dim3(BH * nsplit), dim3(512), LDS, s, p);
+  return ln3d_check_launch();
+}
+
 extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   if (!a || !a->Q || !a->K || !a->Vt || !a->O) return LN3D_ERR_BAD_ARG;
   if (a->Nk <= 0 || a->Nq <= 0 || a->Nk_pad % 64 != 0 || a->Nk_pad < a->Nk || a->Nq_pad < a->Nq) return LN3D_ERR_BAD_ARG;
@@ -461,6 +839,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   p.ldo = a->ldo;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.causal = a->causal ? 1 : 0;
+  p.nsplit = 1;
   hipStream_t s = (hipStream_t)stream;
   // causal masking exists in the short-sequence kernel only (its one user is the 77-token CLIP text tower)
   if (a->causal && !(a->Dh == 64 && a->Nk <= 128)) return LN3D_ERR_UNSUPPORTED;
@@ -470,6 +849,10 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
     // the query-projection GEMM anyway, LN3D_EPI_CROSS_ATTN), so it is opt-in there: LN3D_ATTN_SHORT=1.
     const char* force = getenv("LN3D_ATTN_SHORT");
     if (a->Nk <= 128 && (a->causal || (force && force[0] == '1'))) return launch_attn_short(p, s);
+    if ((a->Nk & 255) == 0 && a->Nk_pad == a->Nk) {
+      const char* ver = getenv("LN3D_ATTN_V");          // measurement switch: 2 = the ring kernel above for these shapes too
+      if (!(ver && ver[0] == '2')) return launch_attn_stream(p, s);
+    }
     return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
   }
   if (a->Dh == 128) return launch_attn<128, 2>(p, s);

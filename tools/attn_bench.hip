@@ -1,0 +1,116 @@
+// Stand-alone self-checking benchmark of ln3d_attention_bf16 (GPU box; build in the container, the binary ships with gpurun):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/attn_bench.hip -o build/attn_bench && build/attn_bench
+// For every case the kernel variants (LN3D_ATTN_V / LN3D_ATTN_NW measurement switches of csrc/attention.hip) are timed with
+// HIP events on random data and their output is compared, element by element, with a naive fp32 kernel on the SAME bf16
+// operands.  One key row is spiked against one query row per head so the deferred-rebase branch is exercised.
+#include "../ln3diff_amd/csrc/attention.hip"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+__global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, float* O, int H, int Nq, int Nqp, int Nk, int Nkp, int Dh,
+                           float scale) {
+  const int q = blockIdx.x, bh = blockIdx.y, d = threadIdx.x;          // one thread per output dim
+  extern __shared__ float sc[];                                         // Nk scores
+  const bf16_t* qp = Q + ((int64_t)bh * Nqp + q) * Dh;
+  for (int k = threadIdx.x; k < Nk; k += blockDim.x) {
+    const bf16_t* kp = K + ((int64_t)bh * Nkp + k) * Dh;
+    float s = 0.f;
+    for (int i = 0; i < Dh; ++i) s += bf2f(qp[i]) * bf2f(kp[i]);
+    sc[k] = s * scale;
+  }
+  __syncthreads();
+  float mx = -3e38f;
+  for (int k = 0; k < Nk; ++k) mx = fmaxf(mx, sc[k]);
+  float l = 0.f, o = 0.f;
+  for (int k = 0; k < Nk; ++k) {
+    const float pv = expf(sc[k] - mx);
+    const int kp = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1);         // V^T key order of the ABI
+    l += pv;
+    o += pv * bf2f(Vt[((int64_t)bh * Dh + d) * Nkp + kp]);
+  }
+  const int b = bh / H, h = bh - b * H;
+  O[((int64_t)b * Nq + q) * (H * Dh) + h * Dh + d] = o / l;
+}
+
+static uint16_t f2bf_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float frand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xffffff) / 8388608.0f - 1.0f; }
+
+struct Case { int B, H, Nq, Nk; };
+
+int main() {
+  const int Dh = 64;
+  const Case cases[] = {{16, 16, 768, 768}, {16, 16, 1024, 1024}, {2, 16, 768, 768}, {1, 4, 700, 1000}, {2, 3, 300, 832}, {1, 2, 257, 257}};
+  const struct { const char* name; const char* v; const char* nw; } variants[] = {
+      {"r1 ring kernel", "2", nullptr}, {"stream kernel", "3", nullptr}};
+  const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
+  int ci = 0;
+  for (const Case& c : cases) {
+    if (ci++ >= ncases) break;
+    const int Nqp = (c.Nq + 63) / 64 * 64, Nkp = (c.Nk + 63) / 64 * 64, BH = c.B * c.H;
+    const size_t nq = (size_t)BH * Nqp * Dh, nk = (size_t)BH * Nkp * Dh, no = (size_t)c.B * c.Nq * c.H * Dh;
+    std::vector<uint16_t> hq(nq, 0), hk(nk, 0), hv(nk, 0);
+    uint64_t seed = 1234567 + c.Nq * 31 + c.Nk;
+    for (int bh = 0; bh < BH; ++bh) {
+      for (int r = 0; r < c.Nq; ++r) for (int d = 0; d < Dh; ++d) hq[((size_t)bh * Nqp + r) * Dh + d] = f2bf_host(1.5f * frand(seed));
+      for (int r = 0; r < c.Nk; ++r) for (int d = 0; d < Dh; ++d) hk[((size_t)bh * Nkp + r) * Dh + d] = f2bf_host(1.5f * frand(seed));
+      for (int d = 0; d < Dh; ++d) for (int r = 0; r < c.Nk; ++r) {
+        const int rp = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        hv[((size_t)bh * Dh + d) * Nkp + rp] = f2bf_host(frand(seed) + (float)d / Dh);
+      }
+      // spike: a late key equal to 3x query row 3 -> its score outgrows every earlier maximum by far more than 2^8
+      const int ks = c.Nk - 5;
+      for (int d = 0; d < Dh; ++d) {
+        uint32_t u = (uint32_t)hq[((size_t)bh * Nqp + 3) * Dh + d] << 16; float f; memcpy(&f, &u, 4);
+        hk[((size_t)bh * Nkp + ks) * Dh + d] = f2bf_host(3.0f * f);
+      }
+    }
+    void *q, *k, *v, *o; float* oref;
+    hipMalloc(&q, nq * 2); hipMalloc(&k, nk * 2); hipMalloc(&v, nk * 2); hipMalloc(&o, no * 2); hipMalloc(&oref, no * 4);
+    hipMemcpy(q, hq.data(), nq * 2, hipMemcpyHostToDevice); hipMemcpy(k, hk.data(), nk * 2, hipMemcpyHostToDevice);
+    hipMemcpy(v, hv.data(), nk * 2, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(naive_attn, dim3(c.Nq, BH), dim3(Dh), c.Nk * sizeof(float), 0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       oref, c.H, c.Nq, Nqp, c.Nk, Nkp, Dh, 0.125f);
+    std::vector<float> href(no);
+    hipMemcpy(href.data(), oref, no * 4, hipMemcpyDeviceToHost);
+    ln3d_attn_args a{};
+    a.Q = q; a.K = k; a.Vt = v; a.O = o; a.B = c.B; a.H = c.H; a.Nq = c.Nq; a.Nq_pad = Nqp; a.Nk = c.Nk; a.Nk_pad = Nkp; a.Dh = Dh;
+    a.ldo = c.H * Dh; a.scale = 0.125f;
+    printf("B %d H %d Nq %d Nk %d\n", c.B, c.H, c.Nq, c.Nk);
+    int vi = 0;
+    for (const auto& var : variants) {
+      if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
+      setenv("LN3D_ATTN_V", var.v, 1);
+      if (var.nw) setenv("LN3D_ATTN_NW", var.nw, 1); else unsetenv("LN3D_ATTN_NW");
+      hipMemset(o, 0xff, no * 2);
+      const int rc = ln3d_attention_bf16(&a, nullptr);
+      hipError_t e = hipDeviceSynchronize();
+      if (rc != 0 || e != hipSuccess) { printf("  %-16s FAILED rc %d hip %d\n", var.name, rc, (int)e); return 1; }
+      std::vector<uint16_t> ho(no);
+      hipMemcpy(ho.data(), o, no * 2, hipMemcpyDeviceToHost);
+      double num = 0, den = 0, mxe = 0;
+      for (size_t i = 0; i < no; ++i) {
+        uint32_t u = (uint32_t)ho[i] << 16; float f; memcpy(&f, &u, 4);
+        const double dlt = (double)f - href[i];
+        num += dlt * dlt; den += (double)href[i] * href[i];
+        if (!(std::fabs(dlt) <= mxe)) mxe = std::fabs(dlt);
+      }
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 5; ++i) ln3d_attention_bf16(&a, nullptr);
+      float best = 1e30f, sum = 0.f;
+      for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) ln3d_attention_bf16(&a, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = fminf(best, ms / 20); sum += ms / 20;
+      }
+      const double fl = 4.0 * c.Nq * c.Nk * c.H * Dh * c.B;
+      printf("  %-16s rel-L2 %.2e  max|err| %.2e   %8.1f us avg %8.1f us best  %7.1f TF/s (best)\n", var.name, std::sqrt(num / den), mxe,
+             sum / 5 * 1e3, best * 1e3, fl / (best * 1e-3) / 1e12);
+    }
+    hipFree(q); hipFree(k); hipFree(v); hipFree(o); hipFree(oref);
+  }
+  return 0;
+}
