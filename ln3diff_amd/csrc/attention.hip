@@ -444,30 +444,44 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
   // run into `nxt`; `loads` reads the V^T columns of the current tile and the K rows of the tile after next.
   // MODE 0: next tile with C = -m ; 2: next tile opens the NEXT query block (C = 0, qf already holds its queries) ;
   //      3: nothing follows.
-  // The reference m is only re-based when it has to be: P = exp2(s - m) is summed first and the wave votes on the SUM (a sum
-  // below 2^40 bounds every term; an overflowed exp2 makes it inf), so the common path carries no row-maximum at all.  bf16 and
-  // fp32 keep their relative precision over that range, and softmax is invariant to the reference.
+  // The whole half-step is ONE scheduling region; the re-base vote on the next tile's row maximum closes it.  (Voting on the
+  // SUM of P instead - no row maximum on the common path, 9 instructions fewer - measured 10 % slower: the vote then sits in the
+  // middle of the half-step and the PV MFMAs can no longer be issued under the exps.)
   auto half_step = [&](f32x16& cur, f32x16& nxt, auto mode_tag, const bf16x8 (&kf)[NDS], auto&& loads) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_tag)::value;
     if constexpr (!(LN3D_ATTN_ABL & 32)) loads();
     if constexpr (MODE == 0) qk_tile(nxt, kf, negm);
     if constexpr (MODE == 2) { f32x16 z; _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f; qk_tile(nxt, kf, z); }
-    f32x2 e[8];
     f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
+    bf16x8 pb[2];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      e[jj].x = (LN3D_ATTN_ABL & 1) ? cur[2 * jj] : __builtin_amdgcn_exp2f(cur[2 * jj]);
-      e[jj].y = (LN3D_ATTN_ABL & 1) ? cur[2 * jj + 1] : __builtin_amdgcn_exp2f(cur[2 * jj + 1]);
-      if (jj & 1) psb += e[jj]; else psa += e[jj];
+    for (int s = 0; s < 2; ++s) {
+      union { uint32_t u[4]; bf16x8 v; } cv;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x2 e;
+        e.x = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj]);
+        e.y = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj + 1] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj + 1]);
+        if (jj & 1) psb += e; else psa += e;
+        cv.u[jj] = pack2bf(e.x, e.y);
+      }
+      pb[s] = cv.v;
     }
     psa += psb;
-    float tot = psa.x + psa.y;
-    if constexpr (!(LN3D_ATTN_ABL & 8)) {
-      if (!__all(tot <= 1.0e12f)) {
-        // rare (the first tiles of a query block, outlier keys): move the reference up to this tile's row maximum and redo its P
-        float mx = tile_max(cur);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float delta = fmaxf(mx, 0.f);
+    l_run += psa.x + psa.y;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        if constexpr (LN3D_ATTN_ABL & 2) { asm volatile("" :: "v"(vf[s * NDT + dt]), "v"(pb[s])); } else
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s * NDT + dt], pb[s], oacc[dt], 0, 0, 0);
+      }
+    if constexpr (MODE == 0 && !(LN3D_ATTN_ABL & 8)) {
+      // deferred re-base (wave-uniform, rare after the first tiles): scores of the next tile outgrow the reference by > 2^8
+      const float mx = tile_max(nxt);
+      if (!__all(mx <= 8.0f)) {
+        const float mxx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = fmaxf(mxx, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-delta);
         l_run *= alpha;
 #pragma unroll
@@ -476,35 +490,10 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
           for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[r] -= delta;
-        if constexpr (MODE == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) nxt[r] -= delta;   // computed against the old reference
-        }
-        tot = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          e[jj].x = __builtin_amdgcn_exp2f(cur[2 * jj] - delta);
-          e[jj].y = __builtin_amdgcn_exp2f(cur[2 * jj + 1] - delta);
-          tot += e[jj].x + e[jj].y;
-        }
+        for (int r = 0; r < 16; ++r) nxt[r] -= delta;
       }
     }
-    l_run += tot;
-    bf16x8 pb[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      union { uint32_t u[4]; bf16x8 v; } cv;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) cv.u[jj] = pack2bf(e[4 * s + jj].x, e[4 * s + jj].y);
-      pb[s] = cv.v;
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        if constexpr (LN3D_ATTN_ABL & 2) { asm volatile("" :: "v"(vf[s * NDT + dt]), "v"(pb[s])); } else
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s * NDT + dt], pb[s], oacc[dt], 0, 0, 0);
-      }
   };
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;

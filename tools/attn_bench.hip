@@ -42,7 +42,7 @@ struct Case { int B, H, Nq, Nk; };
 int main() {
   const int Dh = 64;
   const Case cases[] = {{16, 16, 768, 768}, {16, 16, 1024, 1024}, {2, 16, 768, 768}, {1, 4, 700, 1000}, {2, 3, 300, 832}, {1, 2, 257, 257}};
-  const struct { const char* name; const char* v; const char* nw; } variants[] = {
+  const struct { const char* name; const char* v; const char* qt; } variants[] = {
       {"r1 ring kernel", "2", nullptr}, {"stream kernel", "3", nullptr}};
   const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
   int ci = 0;
@@ -81,8 +81,8 @@ int main() {
     int vi = 0;
     for (const auto& var : variants) {
       if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
-      setenv("LN3D_ATTN_V", var.v, 1);
-      if (var.nw) setenv("LN3D_ATTN_NW", var.nw, 1); else unsetenv("LN3D_ATTN_NW");
+      if (var.v) setenv("LN3D_ATTN_V", var.v, 1); else unsetenv("LN3D_ATTN_V");
+      if (var.qt) setenv("LN3D_ATTN_QT", var.qt, 1); else unsetenv("LN3D_ATTN_QT");
       hipMemset(o, 0xff, no * 2);
       const int rc = ln3d_attention_bf16(&a, nullptr);
       hipError_t e = hipDeviceSynchronize();
