@@ -217,20 +217,28 @@ typedef struct {
   float* wsum;   /* [V,1,res,res] */
   /* scratch */
   float* ray_limits;  /* [V*M*2]  */
-  float* scalars;     /* [LN3D_RENDER_SCRATCH_FLOATS]: batch-global min/max words + packed decoder     */
-  /* optional debug outputs (may be NULL) */
+  float* scalars;     /* [LN3D_RENDER_SCRATCH_FLOATS]: batch-global min/max words + the decoder's MFMA fragment image */
+  /* optional sampling-detail outputs (may be NULL): Triplane.forward's `shape_synthesized` dict, nsr/triplane.py:569-573 */
   float* coarse_sigma; /* [V,M,S] */
   float* fine_depths;  /* [V,M,S] */
+  /* optional explicit rays [V,M,3] each (world units, unit directions): when non-NULL they replace the camera ray generation and
+   * `cams` may be NULL - the seam of ImportanceRenderer.forward(planes, decoder, ray_origins, ray_directions, rendering_options),
+   * nsr/volumetric_rendering/renderer.py:133 */
+  const float* ray_o; const float* ray_d;
+  float* fine_sigma;    /* [V,M,S]   (optional) */
+  float* coarse_coords; /* [V,M,S,3] (optional) sample positions of the coarse pass */
+  float* fine_coords;   /* [V,M,S,3] (optional) sample positions of the importance pass */
 } ln3d_render_args;
 /* Triplane.forward -> ImportanceRenderer.forward -> MipRayMarcher2 (nsr/triplane.py:505-750,
  * nsr/volumetric_rendering/renderer.py:133-307, ray_marcher.py:26-68, ray_sampler.py:262-331),
  * depth_resolution = depth_resolution_importance = 64 (Objaverse preset nsr/script_util.py:761-798). */
 int ln3d_render_triplane(const ln3d_render_args* a, void* stream);
 
-/* triplane_decode_grid / forward_points (vit/vit_triplane.py:2009-2112): points f32 [P,3] -> sigma[P], rgb[P,3] */
+/* triplane_decode_grid / forward_points (vit/vit_triplane.py:2009-2112): points f32 [P,3] -> sigma[P], rgb[P,3].
+ * scalars: caller-owned scratch of LN3D_RENDER_SCRATCH_FLOATS floats (the decoder's fragment image is built into it) */
 int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P,
                       const float* dec_w0, const float* dec_b0, const float* dec_w1, const float* dec_b1,
-                      float box_warp, float* sigma, float* rgb, void* stream);
+                      float box_warp, float* sigma, float* rgb, float* scalars, void* stream);
 
 /* ---------------------------------------------------------------- iso-surface of the sigma grid (mesh export)
  * Replaces mcubes.marching_cubes(sigma[G,G,G], thr) at nsr/train_util_diffusion.py:221 (PyMCubes, third-party, absent:

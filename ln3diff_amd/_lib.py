@@ -49,7 +49,8 @@ class RenderArgs(C.Structure):
                 ("V", i32), ("res", i32), ("dec_w0", vp), ("dec_b0", vp), ("dec_w1", vp), ("dec_b1", vp),
                 ("jitter", vp), ("u_fine", vp), ("box_warp", f32), ("bbox_min", f32), ("bbox_max", f32),
                 ("white_back", i32), ("rgb", vp), ("depth", vp), ("wsum", vp), ("ray_limits", vp),
-                ("scalars", vp), ("coarse_sigma", vp), ("fine_depths", vp)]
+                ("scalars", vp), ("coarse_sigma", vp), ("fine_depths", vp), ("ray_o", vp), ("ray_d", vp),
+                ("fine_sigma", vp), ("coarse_coords", vp), ("fine_coords", vp)]
 
 
 _lib = None
@@ -76,7 +77,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 3
+    assert L.ln3d_abi_version() == 4
     return True
 
 

@@ -277,11 +277,10 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 //    exp2 / sum / pack work of the current one, whose PV MFMAs run under the row-maximum test of the next).
 //  * O leaves through a wave-private staging region beside the ring (the ring never retires here); the next query block's
 //    queries arrive in the same region by LDS-DMA one step ahead.
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// max of three (the compiler selects v_max3_f32).  NOT inline asm: hipcc pads no hazards inside an asm statement, and a
+// v_max3 placed by hand right behind the S^T MFMAs read their accumulators before the matrix pipe had written them back -
+// results stayed within tolerance but differed from run to run (tools/attn_bench.hip now checks repeated launches bitwise).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
   constexpr int DH = 64, NDS = 4, NDT = 2;
@@ -452,23 +451,21 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
     if constexpr (!(LN3D_ATTN_ABL & 32)) loads();
     if constexpr (MODE == 0) qk_tile(nxt, kf, negm);
     if constexpr (MODE == 2) { f32x16 z; _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f; qk_tile(nxt, kf, z); }
-    f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       union { uint32_t u[4]; bf16x8 v; } cv;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        f32x2 e;
-        e.x = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj]);
-        e.y = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj + 1] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj + 1]);
-        if (jj & 1) psb += e; else psa += e;
-        cv.u[jj] = pack2bf(e.x, e.y);
+        const float e0 = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj]);
+        const float e1 = (LN3D_ATTN_ABL & 1) ? cur[8 * s + 2 * jj + 1] : __builtin_amdgcn_exp2f(cur[8 * s + 2 * jj + 1]);
+        if (jj & 1) { ps2 += e0; ps3 += e1; } else { ps0 += e0; ps1 += e1; }
+        cv.u[jj] = pack2bf(e0, e1);
       }
       pb[s] = cv.v;
     }
-    psa += psb;
-    l_run += psa.x + psa.y;
+    l_run += (ps0 + ps1) + (ps2 + ps3);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll

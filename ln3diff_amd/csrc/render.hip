@@ -11,21 +11,42 @@
 //  * gather phase : 8 lanes per sample point, lane (g = lane>>3, c4 = lane&7) fetches channels 4c4..4c4+3
 //    of the 12 taps of point 8*it+g from CHANNEL-LAST planes [3][H][W][32] -> every wave-level load
 //    instruction touches 8 fully-used 128-B texels (coalesced), instead of 64 partially-used lines.
-//    The interpolated 32-vector is transposed through a per-wave LDS tile (row stride 36 floats,
-//    conflict-free for ds_read_b128) ...
-//  * MLP phase    : ... and each lane then runs the 32->64->4 decoder for ITS sample with the weights as
-//    wave-uniform scalar operands (s_load through the scalar cache; no LDS / VGPR traffic for weights).
+//    The interpolated 32-vector goes to a per-wave LDS tile as TWO bf16 rows (hi = truncated fp32, lo = bf16(f - hi)),
+//    128 bytes per point, 16-byte chunks XOR-swizzled ...
+//  * MLP phase    : ... which is the B operand of v_mfma_f32_32x32x16_bf16: the 32 -> 64 -> 4 decoder of the wave's 64 points
+//    runs on the matrix pipe (2 x (12 + 12) MFMAs per pass instead of 2 304 scalar-operand FMAs per lane).  Products are
+//    split hi*hi + hi*lo + lo*hi (error ~2^-16 relative: the fp32 parity of the renderer, 1e-5, is kept); weights are split
+//    once per launch into A fragments (render_init_kernel) and staged in the workgroup's LDS; the hidden bias is the C
+//    operand of the first MFMA; softplus runs in the log2 domain (log2 e folded into layer 1, ln 2 into layer 2).
 //  * compositing  : wavefront-level: neighbours by DPP/shuffle, transmittance by a wave prefix product,
 //    cdf by a wave prefix sum, searchsorted by a 6-step binary search on the per-wave LDS copy of the
 //    cdf, the coarse+fine merge by rank counting (no sort), final sums by wave reductions.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ln3d.h"
 
 #define NS 64            // samples per pass (coarse == fine == 64, Objaverse preset)
-#define FROW 36          // floats per LDS feature row (32 + 4 pad)
-#define WAVE_LDS_FLOATS (NS * FROW)   // 2304 floats = 9216 B per wave
-#define DEC_OFF 16       // scalars[DEC_OFF..] = packed decoder: w0g[64*32], b0[64], w1g[4*64], b1[4]
-#define DEC_FLOATS (64 * 32 + 64 + 4 * 64 + 4)
+#define WAVE_LDS_BYTES 8192           // per wave: 64 points x (64 B hi + 64 B lo) feature rows; reused for cdf / merge arrays
+#define WAVE_LDS_FLOATS (WAVE_LDS_BYTES / 4)
+// scalars[]: [0..15] batch-global words, then the decoder image that every workgroup copies into its LDS:
+//   A1  : 8 fragments (split s, hidden tile jt, k-step ks) x 64 lanes x 16 B           at DEC_A1  (8 KB)
+//   A2  : rows 0-3 only: [split s][k-step s2][hi][output o] x 16 B (other rows are zero)  at DEC_A2  (1 KB)
+//   Z   : 16 zero bytes (the A2 fragment of the lanes whose row is >= 4)                  at DEC_Z
+//   B0  : hidden bias as C fragments [jt][hi][16] f32 (pre-multiplied by log2 e)         at DEC_B0  (256 B)
+//   B1  : output bias [4] f32                                                            at DEC_B1  (16 B)
+#define DEC_OFF 16
+#define DEC_A1 0
+#define DEC_A2 8192
+#define DEC_Z (8192 + 1024)
+#define DEC_B0 (8192 + 1024 + 16)
+#define DEC_B1 (DEC_B0 + 256)
+#define DEC_BYTES (DEC_B1 + 16)
+#define DEC_FLOATS (DEC_BYTES / 4)
+static_assert(DEC_OFF + DEC_FLOATS <= LN3D_RENDER_SCRATCH_FLOATS, "decoder image must fit the caller's scratch");
+
+#ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
+#define LN3D_RENDER_ABL 0
+#endif
 
 __device__ __forceinline__ uint32_t enc_f(float f) {
   uint32_t u = __float_as_uint(f);
@@ -51,6 +72,8 @@ struct RenderP {
   float* rgb; float* depth; float* wsum;
   float* ray_limits; uint32_t* scal_u; const float* dec;
   float* coarse_sigma; float* fine_depths;
+  const float* ray_o; const float* ray_d;          // optional explicit rays [V, M, 3] (ImportanceRenderer.forward seam)
+  float* fine_sigma; float* coarse_coords; float* fine_coords;
 };
 
 // ------------------------------------------------------------------ ray generation + AABB limits
@@ -88,18 +111,46 @@ __device__ __forceinline__ void ray_box(const float o[3], const float d[3], floa
   tmax_o = valid ? tmax : -2.0f;
 }
 
+// hidden index that accumulator register r of lane-half hi holds in hidden tile jt (MFMA 32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+// hi = fp32 truncated to bf16 (exact), lo = bf16(f - hi) (RNE): f ~ hi + lo to 2^-16 relative
+__device__ __forceinline__ void split_bf16(float f, bf16_t& h, bf16_t& l) {
+  const uint32_t u = __float_as_uint(f) & 0xffff0000u;
+  h = (bf16_t)(u >> 16);
+  l = f2bf(f - __uint_as_float(u));
+}
+
+// One launch per render call: resets the batch-global words and builds the decoder's LDS image (see DEC_* above).
+//   FullyConnectedLayer weight_gain 1/sqrt(fan_in) (nsr/networks_stylegan2.py:122-157) is applied here; layer 1 (and its bias)
+//   are pre-multiplied by log2(e) and layer 2 by ln(2): softplus(x) = ln2 * log2(1 + 2^(x log2 e)).
 __global__ void render_init_kernel(uint32_t* scal_u, float* dec, const float* w0, const float* b0, const float* w1, const float* b1) {
-  const int t = threadIdx.x + blockIdx.x * blockDim.x;
+  const int t = threadIdx.x + blockIdx.x * blockDim.x, nt = blockDim.x * gridDim.x;
   if (t == 0) { scal_u[0] = 0xffffffffu; scal_u[1] = 0u; scal_u[2] = 0xffffffffu; scal_u[3] = 0u; scal_u[4] = 0u; }
-  const float g0 = 1.0f / sqrtf(32.0f), g1 = 1.0f / sqrtf(64.0f);   // FullyConnectedLayer weight_gain
-  for (int i = t; i < DEC_FLOATS; i += blockDim.x * gridDim.x) {
-    float v;
-    if (i < 2048) v = w0[i] * g0;
-    else if (i < 2048 + 64) v = b0[i - 2048];
-    else if (i < 2048 + 64 + 256) v = w1[i - 2112] * g1;
-    else v = b1[i - 2368];
-    dec[i] = v;
+  const float g0 = 1.0f / sqrtf(32.0f) * 1.4426950408889634f, g1 = 1.0f / sqrtf(64.0f) * 0.6931471805599453f;
+  char* img = reinterpret_cast<char*>(dec);
+  // A1 fragment (s, jt, ks), lane (row = l31, hi): W0[jt*32 + l31][ks*16 + 8*hi + e], e = 0..7
+  for (int i = t; i < 8 * 64 * 8; i += nt) {
+    const int e = i & 7, lane = (i >> 3) & 63, f = i >> 9;
+    const int sp = f >> 2, jt = (f >> 1) & 1, ks = f & 1, l31 = lane & 31, hi = lane >> 5;
+    bf16_t h, l;
+    split_bf16(w0[(jt * 32 + l31) * 32 + ks * 16 + 8 * hi + e] * g0, h, l);
+    reinterpret_cast<bf16_t*>(img + DEC_A1)[i] = sp ? l : h;
   }
+  // A2 [s][s2][hi][o][e]: W1[o][hidden of k-slot (hi, e) in k-step s2] = the hidden index whose softplus sits in accumulator
+  // register 8*(s2&1)+e of hidden tile s2>>1 of that lane-half
+  for (int i = t; i < 2 * 4 * 2 * 4 * 8; i += nt) {
+    const int e = i & 7, o = (i >> 3) & 3, hi = (i >> 5) & 1, s2 = (i >> 6) & 3, sp = i >> 8;
+    const int hid = (s2 >> 1) * 32 + acc_row(8 * (s2 & 1) + e, hi);
+    bf16_t h, l;
+    split_bf16(w1[o * 64 + hid] * g1, h, l);
+    reinterpret_cast<bf16_t*>(img + DEC_A2)[i] = sp ? l : h;
+  }
+  for (int i = t; i < 4; i += nt) reinterpret_cast<uint32_t*>(img + DEC_Z)[i] = 0u;
+  for (int i = t; i < 2 * 2 * 16; i += nt) {
+    const int r = i & 15, hi = (i >> 4) & 1, jt = i >> 5;
+    reinterpret_cast<float*>(img + DEC_B0)[i] = b0[jt * 32 + acc_row(r, hi)] * 1.4426950408889634f;
+  }
+  for (int i = t; i < 4; i += nt) reinterpret_cast<float*>(img + DEC_B1)[i] = b1[i];
 }
 
 __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_half) {
@@ -110,7 +161,12 @@ __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_ha
   if (ray < nr) {
     const int v = (int)(ray / M), pix = (int)(ray % M);
     float o[3], d[3], a, b;
-    make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    if (p.ray_o) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { o[ax] = p.ray_o[3 * ray + ax]; d[ax] = p.ray_d[3 * ray + ax]; }
+    } else {
+      make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    }
     ray_box(o, d, box_half, a, b);
     p.ray_limits[2 * ray] = a; p.ray_limits[2 * ray + 1] = b;
     if (b > a) { tmn = a; tmx = a; any = 1; }
@@ -126,9 +182,15 @@ __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_ha
 
 // ------------------------------------------------------------------ gather + decoder for the wave's 64 points
 // in : this lane's point (px,py,pz) in world units.  out: rgb[3], sigma (bbox filter applied).
-__device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, float* feat /*per-wave LDS*/,
-                                        const float* __restrict__ dec, float px, float py, float pz, int lane,
-                                        float rgb[3], float& sigma) {
+// wl = the wave's 8 KB of LDS, cimg = the workgroup's copy of the decoder image (DEC_*).
+typedef __attribute__((address_space(3))) const bf16x8 lds_bfrag_t;
+__device__ __forceinline__ float softplus_log2(float x) {   // log2(1 + 2^x); x carries log2(e), the caller's next layer ln(2)
+  const float y = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(x));
+  return x > 28.853900817779268f ? x : y;                     // torch softplus threshold 20, in log2 units
+}
+
+__device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, char* wl, const char* cimg,
+                                        float px, float py, float pz, int lane, float rgb[3], float& sigma) {
   const int g = lane >> 3, c4 = lane & 7;
   const float sx = px * p.coord_scale, sy = py * p.coord_scale, sz = pz * p.coord_scale;
   const int64_t plane_stride = (int64_t)p.H * p.W * 32;
@@ -146,54 +208,124 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
       const int x0 = (int)fx0, y0 = (int)fy0;
       const float w_nw = (fx0 + 1.f - ix) * (fy0 + 1.f - iy), w_ne = (ix - fx0) * (fy0 + 1.f - iy);
       const float w_sw = (fx0 + 1.f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
-      const float* base = planes + pl * plane_stride + c4 * 4;
+      // branch-free taps: out-of-range texels are read at a clamped (valid) address and weighted by 0, so the 12 loads of an
+      // iteration are issued back to back (conditional loads cost one L2 round trip each: the compiler waits per branch)
       const bool xin0 = x0 >= 0 && x0 < p.W, xin1 = x0 + 1 >= 0 && x0 + 1 < p.W;
       const bool yin0 = y0 >= 0 && y0 < p.H, yin1 = y0 + 1 >= 0 && y0 + 1 < p.H;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xin0 && yin0) t = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * p.W + x0) * 32);
-      s.x = t.x * w_nw; s.y = t.y * w_nw; s.z = t.z * w_nw; s.w = t.w * w_nw;
-      t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xin1 && yin0) t = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * p.W + x0 + 1) * 32);
-      s.x += t.x * w_ne; s.y += t.y * w_ne; s.z += t.z * w_ne; s.w += t.w * w_ne;
-      t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xin0 && yin1) t = *reinterpret_cast<const float4*>(base + ((int64_t)(y0 + 1) * p.W + x0) * 32);
-      s.x += t.x * w_sw; s.y += t.y * w_sw; s.z += t.z * w_sw; s.w += t.w * w_sw;
-      t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xin1 && yin1) t = *reinterpret_cast<const float4*>(base + ((int64_t)(y0 + 1) * p.W + x0 + 1) * 32);
-      s.x += t.x * w_se; s.y += t.y * w_se; s.z += t.z * w_se; s.w += t.w * w_se;
+      const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x0 + 1, 0), p.W - 1);
+      const int yc0 = min(max(y0, 0), p.H - 1), yc1 = min(max(y0 + 1, 0), p.H - 1);
+      const float a_nw = (xin0 && yin0) ? w_nw : 0.f, a_ne = (xin1 && yin0) ? w_ne : 0.f;
+      const float a_sw = (xin0 && yin1) ? w_sw : 0.f, a_se = (xin1 && yin1) ? w_se : 0.f;
+      const float* base = planes + pl * plane_stride + c4 * 4;
+      float4 t0, t1, t2, t3;
+      if constexpr (!(LN3D_RENDER_ABL & 2)) {
+        t0 = *reinterpret_cast<const float4*>(base + (yc0 * p.W + xc0) * 32);
+        t1 = *reinterpret_cast<const float4*>(base + (yc0 * p.W + xc1) * 32);
+        t2 = *reinterpret_cast<const float4*>(base + (yc1 * p.W + xc0) * 32);
+        t3 = *reinterpret_cast<const float4*>(base + (yc1 * p.W + xc1) * 32);
+      } else {
+        t0 = t1 = t2 = t3 = make_float4(ix, iy, gx, gy);
+      }
+      // same evaluation order as the reference's grid_sample: ((nw + ne) + sw) + se per channel
+      float4 s;
+      s.x = t0.x * a_nw; s.y = t0.y * a_nw; s.z = t0.z * a_nw; s.w = t0.w * a_nw;
+      s.x += t1.x * a_ne; s.y += t1.y * a_ne; s.z += t1.z * a_ne; s.w += t1.w * a_ne;
+      s.x += t2.x * a_sw; s.y += t2.y * a_sw; s.z += t2.z * a_sw; s.w += t2.w * a_sw;
+      s.x += t3.x * a_se; s.y += t3.y * a_se; s.z += t3.z * a_se; s.w += t3.w * a_se;
       acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
     }
-    const float third = 1.0f / 3.0f;  // mean over the 3 planes (torch: sum / 3)
-    acc.x = acc.x / 3.0f; acc.y = acc.y / 3.0f; acc.z = acc.z / 3.0f; acc.w = acc.w / 3.0f;
-    (void)third;
-    *reinterpret_cast<float4*>(feat + src * FROW + c4 * 4) = acc;
+    // mean over the 3 planes.  torch divides (sum / 3); a multiply by the fp32 reciprocal differs by <= 1 ulp - far inside the
+    // renderer's 1e-5 parity - and saves four IEEE division sequences (~40 VALU) per iteration
+    const float third = 0.333333343267440796f;
+    acc.x *= third; acc.y *= third; acc.z *= third; acc.w *= third;
+    // feature row of point src: chunks 0-3 = bf16 hi of channels 0-31, chunks 4-7 = bf16 lo; 16-byte chunk c at c ^ ((src >> 1) & 7)
+    const uint32_t u0 = __float_as_uint(acc.x) & 0xffff0000u, u1 = __float_as_uint(acc.y) & 0xffff0000u;
+    const uint32_t u2 = __float_as_uint(acc.z) & 0xffff0000u, u3 = __float_as_uint(acc.w) & 0xffff0000u;
+    uint2 hv, lv;
+    hv.x = (u0 >> 16) | u1; hv.y = (u2 >> 16) | u3;
+    lv.x = pack2bf(acc.x - __uint_as_float(u0), acc.y - __uint_as_float(u1));
+    lv.y = pack2bf(acc.z - __uint_as_float(u2), acc.w - __uint_as_float(u3));
+    const int key = (src >> 1) & 7;
+    char* row = wl + src * 128 + (c4 & 1) * 8;
+    *reinterpret_cast<uint2*>(row + (((c4 >> 1) ^ key) << 4)) = hv;
+    *reinterpret_cast<uint2*>(row + (((4 + (c4 >> 1)) ^ key) << 4)) = lv;
   }
   wave_sync();
-  float f[32];
+  const int l31 = lane & 31, hi = lane >> 5;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (!(LN3D_RENDER_ABL & 1)) {
+    const uint32_t cb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)cimg;
+    const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)wl;
+    const float4 b1 = *reinterpret_cast<const float4*>(cimg + DEC_B1);
+#pragma unroll 1
+    for (int pt = 0; pt < 2; ++pt) {
+      const int prow = pt * 32 + l31, key = (prow >> 1) & 7;
+      bf16x8 bh[2], bl[2];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(feat + lane * FROW + k * 4);
-    f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
-  }
-  wave_sync();   // feat may be overwritten by the caller / next pass
-  const float* w0 = dec; const float* b0 = dec + 2048; const float* w1 = dec + 2112; const float* b1 = dec + 2368;
-  float o0 = b1[0], o1 = b1[1], o2 = b1[2], o3 = b1[3];
-#pragma unroll 4
-  for (int j = 0; j < 64; ++j) {
-    float h = b0[j];
+      for (int ks = 0; ks < 2; ++ks) {
+        bh[ks] = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((2 * ks + hi) ^ key) << 4));
+        bl[ks] = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((4 + 2 * ks + hi) ^ key) << 4));
+      }
+      f32x16 oacc;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) h += f[k] * w0[j * 32 + k];
-    h = softplus_fast(h);
-    o0 += h * w1[j]; o1 += h * w1[64 + j]; o2 += h * w1[128 + j]; o3 += h * w1[192 + j];
+      for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        // hidden tile jt: 32 hidden units x the 32 points, bias as the C operand, then its two k-steps of layer 2
+        f32x16 hacc;
+        const float4* bp = reinterpret_cast<const float4*>(cimg + DEC_B0 + (jt * 2 + hi) * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 b = bp[q]; hacc[4 * q] = b.x; hacc[4 * q + 1] = b.y; hacc[4 * q + 2] = b.z; hacc[4 * q + 3] = b.w; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((0 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
+          const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((1 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], hacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = softplus_log2(hacc[r]);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const int s2 = 2 * jt + sh;
+          union { uint32_t u[4]; bf16x8 v; } ph, pl_;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f0 = hacc[8 * sh + 2 * e], f1 = hacc[8 * sh + 2 * e + 1];
+            const uint32_t w0 = __float_as_uint(f0) & 0xffff0000u, w1 = __float_as_uint(f1) & 0xffff0000u;
+            ph.u[e] = (w0 >> 16) | w1;
+            pl_.u[e] = pack2bf(f0 - __uint_as_float(w0), f1 - __uint_as_float(w1));
+          }
+          const uint32_t a2h = l31 < 4 ? cb + DEC_A2 + (((0 * 4 + s2) * 2 + hi) * 4 + l31) * 16 : cb + DEC_Z;
+          const uint32_t a2l = l31 < 4 ? cb + DEC_A2 + (((1 * 4 + s2) * 2 + hi) * 4 + l31) * 16 : cb + DEC_Z;
+          const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)a2h;
+          const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)a2l;
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph.v, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl_.v, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph.v, oacc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // keep the two hidden tiles apart: one set of fragments live at a time
+      }
+      // rows 0-3 = (sigma, r, g, b) of point pt*32 + l31, in registers 0-3 of lanes 0-31
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = __shfl(oacc[k], l31, 64);
+        if (hi == pt) o[k] = v;
+      }
+    }
+    o[0] += b1.x; o[1] += b1.y; o[2] += b1.z; o[3] += b1.w;
+  } else {
+    o[0] = sx; o[1] = sy; o[2] = sz; o[3] = sx + sy;
   }
+  wave_sync();   // the wave's LDS may be overwritten by the caller / next pass
   const bool inb = px >= p.bbox_min && px <= p.bbox_max && py >= p.bbox_min && py <= p.bbox_max && pz >= p.bbox_min &&
                    pz <= p.bbox_max;
   const float sg_fill = -3.4028234663852886e38f / 3.0f;   // nan_to_num(-inf) / SAFE_GUARD
-  sigma = inb ? o0 : sg_fill;
-  rgb[0] = inb ? (1.0f / (1.0f + __expf(-o1))) * 1.002f - 0.001f : 0.f;
-  rgb[1] = inb ? (1.0f / (1.0f + __expf(-o2))) * 1.002f - 0.001f : 0.f;
-  rgb[2] = inb ? (1.0f / (1.0f + __expf(-o3))) * 1.002f - 0.001f : 0.f;
+  sigma = inb ? o[0] : sg_fill;
+  rgb[0] = inb ? (1.0f / (1.0f + __expf(-o[1]))) * 1.002f - 0.001f : 0.f;
+  rgb[1] = inb ? (1.0f / (1.0f + __expf(-o[2]))) * 1.002f - 0.001f : 0.f;
+  rgb[2] = inb ? (1.0f / (1.0f + __expf(-o[3]))) * 1.002f - 0.001f : 0.f;
 }
 
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {   // exclusive prefix product over lanes
@@ -210,10 +342,22 @@ __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
   return x;
 }
 
-__global__ __launch_bounds__(256) void render_kernel(RenderP p, const float* __restrict__ dec) {
+// the workgroup's copy of the decoder image (built once per launch by render_init_kernel) behind the 4 wave regions
+__device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const float* dec_img) {
+  char* cimg = lds_bytes + 4 * WAVE_LDS_BYTES;
+  const uint4* src = reinterpret_cast<const uint4*>(dec_img);
+  for (int i = threadIdx.x; i < DEC_BYTES / 16; i += blockDim.x) reinterpret_cast<uint4*>(cimg)[i] = src[i];
+  __syncthreads();
+  return cimg;
+}
+#define RENDER_LDS_BYTES (4 * WAVE_LDS_BYTES + DEC_BYTES)
+
+__global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float* feat = lds + wid * WAVE_LDS_FLOATS;       // 2304 floats; reused for cdf/bins/merge arrays between shading passes
+  const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec);
+  float* feat = lds + wid * WAVE_LDS_FLOATS;       // 2048 floats; reused for cdf/bins/merge arrays between shading passes
+  char* wl = reinterpret_cast<char*>(feat);
   const int M = p.res * p.res;
   const int64_t nrays = (int64_t)p.V * M;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -224,7 +368,12 @@ __global__ __launch_bounds__(256) void render_kernel(RenderP p, const float* __r
   for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < nrays; ray += nwaves) {
     const int v = (int)(ray / M), pix = (int)(ray % M);
     float o[3], d[3];
-    make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    if (p.ray_o) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { o[ax] = p.ray_o[3 * ray + ax]; d[ax] = p.ray_d[3 * ray + ax]; }
+    } else {
+      make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    }
     float t0 = p.ray_limits[2 * ray], t1 = p.ray_limits[2 * ray + 1];
     if (any_valid && !(t1 > t0)) { t0 = gmin; t1 = gmax; }    // renderer.py:151-155 (sic)
     const float* planes = p.planes + (int64_t)p.plane_index[v] * 3 * p.H * p.W * 32;
@@ -234,8 +383,12 @@ __global__ __launch_bounds__(256) void render_kernel(RenderP p, const float* __r
     const float delta = (t1 - t0) / (float)(NS - 1);
     const float zc = (t0 + step * (t1 - t0)) + p.jitter[ray * NS + lane] * delta;
     float rgbc[3], sigc;
-    shade64(p, planes, feat, dec, o[0] + zc * d[0], o[1] + zc * d[1], o[2] + zc * d[2], lane, rgbc, sigc);
+    shade64(p, planes, wl, cimg, o[0] + zc * d[0], o[1] + zc * d[1], o[2] + zc * d[2], lane, rgbc, sigc);
     if (p.coarse_sigma) p.coarse_sigma[ray * NS + lane] = sigc;
+    if (p.coarse_coords) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) p.coarse_coords[(ray * NS + lane) * 3 + ax] = o[ax] + zc * d[ax];
+    }
 
     // ---- coarse ray-march weights (63 intervals: lane i <-> samples i, i+1)
     const float zn = __shfl_down(zc, 1, 64), sn = __shfl_down(sigc, 1, 64);
@@ -290,7 +443,12 @@ __global__ __launch_bounds__(256) void render_kernel(RenderP p, const float* __r
     }
     if (p.fine_depths) p.fine_depths[ray * NS + lane] = zf;
     float rgbf[3], sigf;
-    shade64(p, planes, feat, dec, o[0] + zf * d[0], o[1] + zf * d[1], o[2] + zf * d[2], lane, rgbf, sigf);
+    shade64(p, planes, wl, cimg, o[0] + zf * d[0], o[1] + zf * d[1], o[2] + zf * d[2], lane, rgbf, sigf);
+    if (p.fine_sigma) p.fine_sigma[ray * NS + lane] = sigf;
+    if (p.fine_coords) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) p.fine_coords[(ray * NS + lane) * 3 + ax] = o[ax] + zf * d[ax];
+    }
 
     // ---- merge coarse + fine by rank (replaces cat + torch.sort + gathers)
     float* zc_s = feat; float* zf_s = feat + 64; float* srt = feat + 128;   // srt: 128 x {z, sigma, r, g, b}
@@ -367,10 +525,12 @@ __global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int
 }
 
 extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
-  if (!a || !a->planes || !a->plane_index || !a->cams || !a->jitter || !a->u_fine || !a->rgb || !a->depth || !a->wsum ||
+  if (!a || !a->planes || !a->plane_index || !a->jitter || !a->u_fine || !a->rgb || !a->depth || !a->wsum ||
       !a->ray_limits || !a->scalars || !a->dec_w0 || !a->dec_b0 || !a->dec_w1 || !a->dec_b1)
     return LN3D_ERR_BAD_ARG;
   if (a->V <= 0 || a->res <= 0) return LN3D_ERR_BAD_ARG;
+  if (!a->cams && !(a->ray_o && a->ray_d)) return LN3D_ERR_BAD_ARG;       // cameras, or explicit rays
+  if ((a->ray_o != nullptr) != (a->ray_d != nullptr)) return LN3D_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   RenderP p;
   p.planes = a->planes; p.H = a->H; p.W = a->W; p.plane_index = a->plane_index; p.cams = a->cams; p.V = a->V; p.res = a->res;
@@ -379,22 +539,29 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   p.rgb = a->rgb; p.depth = a->depth; p.wsum = a->wsum; p.ray_limits = a->ray_limits;
   p.scal_u = reinterpret_cast<uint32_t*>(a->scalars); p.dec = a->scalars + DEC_OFF;
   p.coarse_sigma = a->coarse_sigma; p.fine_depths = a->fine_depths;
+  p.ray_o = a->ray_o; p.ray_d = a->ray_d; p.fine_sigma = a->fine_sigma; p.coarse_coords = a->coarse_coords; p.fine_coords = a->fine_coords;
   const int64_t nrays = (int64_t)a->V * a->res * a->res;
-  hipLaunchKernelGGL(render_init_kernel, dim3(4), dim3(256), 0, s, p.scal_u, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
   hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
   int64_t blocks = (nrays + 3) / 4;
   const int64_t cap = 256 * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 4 * WAVE_LDS_FLOATS * sizeof(float), s, p, p.dec);
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, s, p);
   hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays);
   return ln3d_check_launch();
 }
 
 // ------------------------------------------------------------------ point query (sigma / rgb grid), no bbox filter
-__global__ __launch_bounds__(256) void query_points_kernel(RenderP p, const float* __restrict__ dec, const float* pts, int64_t P, float* sigma, float* rgb) {
+__global__ __launch_bounds__(256) void query_points_kernel(RenderP p, const float* pts, int64_t P, float* sigma, float* rgb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float* feat = lds + wid * WAVE_LDS_FLOATS;
+  const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec);
+  char* wl = reinterpret_cast<char*>(lds + wid * WAVE_LDS_FLOATS);
   const int64_t nw = (int64_t)gridDim.x * 4;
   const int64_t ngroups = (P + 63) / 64;
   for (int64_t gidx = (int64_t)blockIdx.x * 4 + wid; gidx < ngroups; gidx += nw) {
@@ -403,30 +570,29 @@ __global__ __launch_bounds__(256) void query_points_kernel(RenderP p, const floa
     if (!ok) i = P - 1;
     const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     float c[3], sg;
-    shade64(p, p.planes, feat, dec, x, y, z, lane, c, sg);
+    shade64(p, p.planes, wl, cimg, x, y, z, lane, c, sg);
     if (ok) { sigma[i] = sg; rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2]; }
   }
 }
 
-// dec scratch for query: caller passes packed decoder via the same init kernel into a static device buffer
-static float* g_query_dec = nullptr;
-
 extern "C" int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P, const float* dec_w0,
                                  const float* dec_b0, const float* dec_w1, const float* dec_b1, float box_warp, float* sigma,
-                                 float* rgb, void* stream) {
-  if (!planes || !points || !sigma || !rgb || P <= 0) return LN3D_ERR_BAD_ARG;
+                                 float* rgb, float* scalars, void* stream) {
+  if (!planes || !points || !sigma || !rgb || !scalars || P <= 0) return LN3D_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (!g_query_dec) {
-    if (hipMalloc(&g_query_dec, (DEC_OFF + DEC_FLOATS) * sizeof(float)) != hipSuccess) return LN3D_ERR_LAUNCH;
-  }
   RenderP p{};
   p.planes = planes; p.H = H; p.W = W; p.coord_scale = (float)(2.0 / (double)box_warp);
   p.bbox_min = -3.0e38f; p.bbox_max = 3.0e38f;
-  p.scal_u = reinterpret_cast<uint32_t*>(g_query_dec); p.dec = g_query_dec + DEC_OFF;
-  hipLaunchKernelGGL(render_init_kernel, dim3(4), dim3(256), 0, s, p.scal_u, g_query_dec + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
+  p.scal_u = reinterpret_cast<uint32_t*>(scalars); p.dec = scalars + DEC_OFF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&query_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, scalars + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
   int64_t blocks = ((P + 63) / 64 + 3) / 4;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)blocks), dim3(256), 4 * WAVE_LDS_FLOATS * sizeof(float), s, p, p.dec, points, P, sigma, rgb);
+  hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, s, p, points, P, sigma, rgb);
   return ln3d_check_launch();
 }
 

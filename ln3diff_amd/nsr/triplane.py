@@ -136,6 +136,7 @@ class Triplane(nn.Module):
         H, W = planes_channel_last_one.shape[-3], planes_channel_last_one.shape[-2]
         sigma = torch.empty(P, 1, device=dev)
         rgb = torch.empty(P, 3, device=dev)
+        scal = torch.empty(RENDER_SCRATCH_FLOATS, device=dev)
         ops.query_points(planes_channel_last_one.contiguous(), H, W, points.contiguous().float(), self._decoder_dev(dev),
-                         self.rendering_kwargs['box_warp'], sigma, rgb)
+                         self.rendering_kwargs['box_warp'], sigma, rgb, scal)
         return {'sigma': sigma, 'rgb': rgb}

@@ -120,21 +120,25 @@ def planes_to_nchw(src, dst, NP, Cc, H, W):
 
 
 def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine, rgb, depth, wsum, ray_limits, scalars,
-                    box_warp=0.9, bbox_min=-0.45, bbox_max=0.45, white_back=True, coarse_sigma=None, fine_depths=None):
+                    box_warp=0.9, bbox_min=-0.45, bbox_max=0.45, white_back=True, coarse_sigma=None, fine_depths=None,
+                    ray_o=None, ray_d=None, fine_sigma=None, coarse_coords=None, fine_coords=None, n_views=None):
+    """cams [V,25] (rays generated in-kernel) or explicit ray_o / ray_d [V, res*res, 3] (then cams may be None)."""
     a = L.RenderArgs()
     a.planes, a.H, a.W, a.plane_index, a.cams = _p(planes_cl), H, W, _p(plane_index), _p(cams)
-    a.V, a.res = cams.shape[0], res
+    a.V, a.res = (cams.shape[0] if cams is not None else n_views), res
     a.dec_w0, a.dec_b0, a.dec_w1, a.dec_b1 = (_p(t) for t in dec)
     a.jitter, a.u_fine = _p(jitter), _p(u_fine)
     a.box_warp, a.bbox_min, a.bbox_max, a.white_back = box_warp, bbox_min, bbox_max, int(white_back)
     a.rgb, a.depth, a.wsum, a.ray_limits, a.scalars = _p(rgb), _p(depth), _p(wsum), _p(ray_limits), _p(scalars)
     a.coarse_sigma, a.fine_depths = _p(coarse_sigma), _p(fine_depths)
+    a.ray_o, a.ray_d, a.fine_sigma, a.coarse_coords, a.fine_coords = _p(ray_o), _p(ray_d), _p(fine_sigma), _p(coarse_coords), _p(fine_coords)
     L.check(L.lib().ln3d_render_triplane(C.byref(a), _stream()), "render_triplane")
 
 
-def query_points(planes_cl, H, W, points, dec, box_warp, sigma, rgb):
+def query_points(planes_cl, H, W, points, dec, box_warp, sigma, rgb, scalars):
+    """scalars: caller-owned f32 scratch of _lib.RENDER_SCRATCH_FLOATS (no allocation inside the library)."""
     L.check(L.lib().ln3d_query_points(_p(planes_cl), H, W, _p(points), C.c_int64(points.shape[0]), *(_p(t) for t in dec),
-                                      C.c_float(box_warp), _p(sigma), _p(rgb), _stream()), "query_points")
+                                      C.c_float(box_warp), _p(sigma), _p(rgb), _p(scalars), _stream()), "query_points")
 
 
 def groupnorm_swish(x, w, b, y, stats, N, HW, Cc, groups=32, eps=1e-6, swish=True):

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Full-size golden vectors (VERDICT r1 "weak" item 1): sequential parity at the benchmarked model sizes, produced by the
+REFERENCE's own Python in the build container (see make_golden.py for the rules; the reference does not travel).
+
+    python tests/golden/make_golden_full.py [full_edm] [full_flow] [render_full] [chain]
+
+  full_edm    DiT-L/2 T23D, EulerEDMSampler(250) + DiscreteDenoiser + VanillaCFG(6.5), B = 1 (network batch 2): final
+              latent and three trajectory points.  ~2 x 8 min on 8 cores (reference + oracle).
+  full_flow   DiT-PixArt-L/2 I23D, transport Sampler.sample_ode('euler', 50) with forward_with_cfg(4.0), B = 1: final latent.
+  render_full one 128^2 and one 256^2 view of the reference Triplane.forward (fp16, sub-sampled) + full-image statistics.
+  chain       BASELINE configs[1] end to end on the tiny models (a20): z(seed 41) -> EulerEDM(10)+CFG -> latent * 0.96806 ->
+              AE(behaviour='decode_after_vae_no_render') -> AE(behaviour='triplane_dec') for 2 cameras @ 32^2, and
+              AE(behaviour='triplane_decode_grid', grid_size=8): what render_video_given_triplane drives.
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402  (installs the shims)
+import make_golden_render as mgr  # noqa: E402
+from ln3diff_amd.synth import synth_input, orbit_cameras  # noqa: E402
+from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec  # noqa: E402
+
+torch.set_grad_enabled(False)
+check, save, load_synth = mg.check, mg.save, mg.load_synth
+
+
+def sec_full_edm():
+    print('== DiT-L/2 T23D: EulerEDM 250 + CFG 6.5, B=1 (reference sgm sampler vs oracle)')
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = mg.build_t23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    z = synth_input('z', (1, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (1, 77, 768), 41), 'vector': synth_input('v', (1, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    steps = 250
+    sampler = EulerEDMSampler(discretization_config=dc, num_steps=steps,
+                              guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG',
+                                             'params': {'scale': 6.5}}, device='cpu')
+    den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                           num_idx=1000, discretization_config=dc, do_append_zero=False, quantize_c_noise=True, flip=True)
+    t0 = time.time()
+    y_ref = sampler(lambda x, s, c: den(lambda xx, t, cc, **kw: m(xx, t, cc), x, s, c), z.clone(), cond, uc)
+    print(f'  reference loop {time.time() - t0:.0f}s; final std {float(y_ref.std()):.3f} finite {bool(torch.isfinite(y_ref).all())}')
+    trace = []
+    t0 = time.time()
+    y_or = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads), z.clone(), cond, uc, steps, 6.5, trace)
+    print(f'  oracle loop {time.time() - t0:.0f}s')
+    check('DiT-L/2 EulerEDM-250 final latent', y_or, y_ref, 5e-4)
+    save('full_edm_ditl2_250', final=y_ref, first=trace[0], s50=trace[50], s125=trace[125], s200=trace[200])
+
+
+def sec_full_flow():
+    print('== DiT-PixArt-L/2 I23D: flow-matching Euler num_steps=50 (49 steps), CFG 4.0, B=1')
+    from transport import create_transport, Sampler
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = mg.build_i23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    tr = create_transport(path_type='Linear', prediction='velocity', snr_type='lognorm')
+    z = synth_input('z', (1, 12, 32, 32), 42)
+    zs = torch.cat([z, z], 0)
+    cond = {'crossattn': synth_input('ca', (1, 256, 2048), 42), 'vector': synth_input('v', (1, 768), 42)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    context = {k: torch.cat([cond[k], uc[k]], 0) for k in cond}
+    fn = Sampler(tr).sample_ode(sampling_method='euler', num_steps=50)
+    t0 = time.time()
+    y_ref = fn(zs.clone(), m.forward_with_cfg, context=context, cfg_scale=4.0)[-1].chunk(2)[0]
+    print(f'  reference loop {time.time() - t0:.0f}s; final std {float(y_ref.std()):.3f}')
+    y_or = osamp.flow_ode_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], kw['cfg_scale'], heads),
+                                 zs.clone(), 50, 'euler', context=context, cfg_scale=4.0).chunk(2)[0]
+    check('DiT-PixArt-L/2 flow euler-50 final latent', y_or, y_ref, 5e-4)
+    save('full_flow_pixartl2_euler50', final=y_ref)
+
+
+def sec_render_full():
+    print('== renderer at the benchmarked resolutions (reference Triplane.forward)')
+    for res in (128, 256):
+        tp = mgr.build_triplane(res)
+        sd = mgr.dense_decoder_sd(0)
+        tp.decoder.load_state_dict(sd, strict=True)
+        planes = synth_input('planes', (1, 96, 128, 128), 3, 4.0)
+        cams = orbit_cameras(8)[[3]]
+        torch.manual_seed(0)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = tp(planes, cams)
+        print(f'  {res}^2: reference {time.time() - t0:.0f}s, mask mean {float(r["image_mask"].mean()):.3f}')
+        st = max(1, res // 64)
+        save(f'render_full_r{res}', image_raw_sub=r['image_raw'][:, :, ::st, ::st].half(),
+             image_depth_sub=r['image_depth'][:, :, ::st, ::st].half(), weights_sub=r['weights_samples'][:, :, ::st, ::st].half(),
+             rgb_mean=r['image_raw'].mean((0, 2, 3)), rgb_sq=(r['image_raw'] ** 2).mean((0, 2, 3)),
+             depth_mean=r['image_depth'].mean(), depth_min=r['image_depth'].min(), depth_max=r['image_depth'].max(),
+             w_mean=r['weights_samples'].mean(), cams=cams, jitter_seed=np.array(0), stride=np.array(st))
+
+
+def sec_chain():
+    print('== configs[1] chain on the tiny models through the reference AE behaviours')
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    from nsr.script_util import AE
+    m = mg.build_t23d(128, 2, 2)
+    sd, _ = load_synth(m, 0)
+    dec = mgr.build_decoder(128, 2, 2)
+    dsd, _ = load_synth(dec, 0)
+    dsd2 = {k: v.clone() for k, v in dec.state_dict().items()}
+    dsd2['triplane_decoder.decoder.net.2.bias'][0] += 4.0           # non-empty volume
+    dec.load_state_dict(dsd2, strict=True)
+    dec.triplane_decoder.neural_rendering_resolution = 32
+    with contextlib.redirect_stdout(io.StringIO()):
+        ae = AE(None, dec, 32, False, False, None, False, dino_version='sd_dit', no_dim_up_mlp=True).eval()   # create_3DAE_model's wiring for the released decoder
+    B = 2
+    torch.manual_seed(41)                                           # th.manual_seed(41); randn(z_shape): sgm_DiffusionEngine.py:457
+    z = torch.randn(B, 12, 32, 32)
+    cond = {'crossattn': synth_input('c', (1, 77, 768), 41).repeat_interleave(B, 0),
+            'vector': synth_input('v', (1, 768), 41).repeat_interleave(B, 0)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    sampler = EulerEDMSampler(discretization_config=dc, num_steps=10,
+                              guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG', 'params': {'scale': 6.5}},
+                              device='cpu')
+    den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                           num_idx=1000, discretization_config=dc, do_append_zero=False, quantize_c_noise=True, flip=True)
+    latent = sampler(lambda x, s, c: den(lambda xx, t, cc, **kw: m(xx, t, cc), x, s, c), z.clone(), cond, uc)
+    planes_in = latent.clone()
+    planes_in *= 0.96806                                            # render_video_given_triplane :188
+    cams = orbit_cameras(8)[[2, 5]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = {'latent_normalized_2Ddiffusion': planes_in[0:1]}
+        d.update(ae(latent=d, behaviour='decode_after_vae_no_render'))
+        frames = []
+        torch.manual_seed(0)
+        for i in range(2):                                          # one camera per call, as the reference's video loop
+            pred = ae(img=None, c=cams[i:i + 1], latent=d, behaviour='triplane_dec')
+            frames.append({k: pred[k].clone() for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask')})
+        grid = ae(latent=d, grid_size=8, behaviour='triplane_decode_grid')
+    print('  latent std %.3f planes std %.3f mask mean %.3f' % (float(latent.std()), float(d['latent_after_vit'].std()),
+                                                              float(frames[0]['image_mask'].mean())))
+    # oracle on the same chain
+    y_or = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2), z.clone(), cond, uc, 10, 6.5, [])
+    check('chain latent', y_or, latent, 2e-4)
+    planes_or = odec.vae_decode(dsd2, planes_in[0:1], 2)
+    check('chain planes', planes_or, d['latent_after_vit'], 1e-4)
+    save('chain_tiny', latent=latent, planes_sub=d['latent_after_vit'][:, :, ::8, ::8],
+         planes_mean=d['latent_after_vit'].mean(), planes_std=d['latent_after_vit'].std(),
+         image_raw=torch.cat([f['image_raw'] for f in frames]), image_depth=torch.cat([f['image_depth'] for f in frames]),
+         weights_samples=torch.cat([f['weights_samples'] for f in frames]), image_mask=torch.cat([f['image_mask'] for f in frames]),
+         grid_sigma=grid['sigma'], grid_rgb=grid['rgb'], cams=cams, z_seed=np.array(41), jitter_seed=np.array(0))
+
+
+SECTIONS = {'full_edm': sec_full_edm, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain}
+
+if __name__ == '__main__':
+    for s in (sys.argv[1:] or list(SECTIONS)):
+        t0 = time.time()
+        SECTIONS[s]()
+        print(f'-- {s} done in {time.time() - t0:.1f}s', flush=True)

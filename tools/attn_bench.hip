@@ -87,8 +87,15 @@ int main() {
       const int rc = ln3d_attention_bf16(&a, nullptr);
       hipError_t e = hipDeviceSynchronize();
       if (rc != 0 || e != hipSuccess) { printf("  %-16s FAILED rc %d hip %d\n", var.name, rc, (int)e); return 1; }
-      std::vector<uint16_t> ho(no);
+      std::vector<uint16_t> ho(no), ho2(no);
       hipMemcpy(ho.data(), o, no * 2, hipMemcpyDeviceToHost);
+      size_t nd = 0;                                      // determinism: repeated launches must agree bit for bit
+      for (int rep = 0; rep < 4; ++rep) {
+        ln3d_attention_bf16(&a, nullptr); hipDeviceSynchronize();
+        hipMemcpy(ho2.data(), o, no * 2, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < no; ++i) nd += ho[i] != ho2[i];
+      }
+      if (nd) printf("  %-16s NONDETERMINISTIC: %zu elements differ over 4 repeats\n", var.name, nd);
       double num = 0, den = 0, mxe = 0;
       for (size_t i = 0; i < no; ++i) {
         uint32_t u = (uint32_t)ho[i] << 16; float f; memcpy(&f, &u, 4);
