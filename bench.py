@@ -44,11 +44,11 @@ def build_models(dev, arch, dec_arch, seed=0, fill=True):
     return dit, dec
 
 
-def roofline_probe(dev, n_net, D, iters=20):
+def roofline_probe(dev, n_net, D, iters=20, tokens=768):
     """Live HIP-event timing of the dominant kernel of the step: the MLP fc1 GEMM (gemm_bf16_kernel<GELU_ERF>,
     M = n_net*768 tokens, N = 4D, K = D) at the workload's exact shape, on the stream it is launched on."""
     from ln3diff_amd import ops
-    M, N, K = n_net * 768, 4 * D, D
+    M, N, K = n_net * tokens, 4 * D, D
     x = (torch.randn(M, K, device=dev) * 1.0).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
     b = torch.randn(N, device=dev) * 0.02
@@ -74,29 +74,35 @@ def roofline_probe(dev, n_net, D, iters=20):
             "algorithmic_flop_per_launch": flops}
 
 
-def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20):
+def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     from ln3diff_amd import ops
-    q = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
+    Nq = Nq or N
+    q = torch.randn(n_net, H, Nq, Dh, device=dev).to(torch.bfloat16)
     k = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
     vt = torch.randn(n_net, H, Dh, N, device=dev).to(torch.bfloat16)
-    o = torch.empty(n_net, N, H * Dh, device=dev, dtype=torch.bfloat16)
+    o = torch.empty(n_net, Nq, H * Dh, device=dev, dtype=torch.bfloat16)
     for _ in range(3):
-        ops.attention(q, k, vt, o, n_net, H, N, N, N, N, Dh)
+        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.attention(q, k, vt, o, n_net, H, N, N, N, N, Dh)
+        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 4.0 * N * N * H * Dh * n_net          # 4*Nq*Nkv*(H*Dh) per sample-layer
+    flops = 4.0 * Nq * N * H * Dh * n_net          # 4*Nq*Nkv*(H*Dh) per sample-layer
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "attn_kernel<64,4> (DiT-L/2 self-attention)", "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
-            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 214.1e6,
-            "traffic_source": "profiles/r1_e_pmc.md"}
+    stream = (N % 256 == 0 and Dh == 64 and not os.environ.get('LN3D_ATTN_V'))
+    return {"kernel": ("attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<64,4>") +
+                      " - DiT self-attention, %d queries x %d keys" % (Nq, N), "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 150e6 if N == 768 else None,
+            "traffic_source": "profiles/r2_attn_pmc.md (K/V re-reads miss the 4 MB XCD L2; instruction-issue bound, see there)"}
 
 
 def render_probe(dev, dec, res=256, V=4, iters=5):
+    """The fused ray-marcher is NOT an HBM-streaming kernel (the 6 MB tri-plane is L2-resident, profiles/r2_render_pmc.md): the
+    honest figures are ms/view against SURVEY.md 8d's 2.7 ms HBM-gather target, the MFMA fraction of its decoder MLP, and the
+    PMC HBM bytes.  `achieved`/`frac` keep the contract's algorithmic-gather-bytes definition for continuity."""
     from ln3diff_amd.synth import orbit_cameras
     tp = dec.triplane_decoder
     pcl = torch.randn(1, 3, 128, 128, 32, device=dev) * 4.0
@@ -115,21 +121,24 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
     pts = V * res * res * 128
     gbytes = pts * 1536.0 / 1e9                    # 3 planes x 4 taps x 32 ch x 4 B per sample point
     ach = gbytes / (ms * 1e-3)
+    mlp_tflops = pts * 2.0 * (32 * 64 + 64 * 4) * 3 / (ms * 1e-3) / 1e12      # bf16x3 split: 3 MFMA products per fp32 product
     return {"kernel": "render_kernel (fused tri-plane ray-march, %dx%d^2 views)" % (V, res), "bound": "hbm",
             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-            "definition": "algorithmic gather bytes (1536 B/sample point); texels are L2/MALL-resident, see DESIGN.md",
-            "ms_per_view": round(ms / V, 3)}
+            "definition": "algorithmic gather bytes (1536 B/sample point) / time; the texels are L2-resident so this is an L2-gather "
+                          "rate, not HBM traffic - judge the kernel on ms_per_view vs target_ms_per_view",
+            "ms_per_view": round(ms / V, 3), "target_ms_per_view": 2.7, "mlp_issued_bf16_tflops": round(mlp_tflops, 1),
+            "traffic": None, "traffic_source": "profiles/r2_render_pmc.md"}
 
 
 def cpu_baseline(arch, steps_total, views, res, B):
     """CPU restatement (oracle/, validated against the reference's own Python in the build container) timed on
     this box's host cores on a bounded sample of the same workload, extrapolated linearly (per-step and per-view
-    costs are constant): 2 timed EDM steps at B=1 (network batch 2, CFG), 1 VAE decode at B=1, 1 view."""
-    from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec
+    costs are constant): 2 timed EulerEDM steps at B=1 (network batch 2, CFG), 1 VAE decode scaled by FLOPs, 1 view."""
+    from oracle import dit as odit, samplers as osamp, render as orender
     from ln3diff_amd.synth import orbit_cameras
     from ln3diff_amd.dit.dit_trilatent import DiT_models
     from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
-    cores = min(os.cpu_count(), 32)       # torch intra-op scaling collapses beyond ~32 threads at these GEMM sizes
+    cores = os.cpu_count()                # SURVEY 8d: all host cores, count stated
     torch.set_num_threads(cores)
     hidden, depth, heads = odit.DIT_CONFIGS[arch]
     t_all = time.time()
@@ -171,10 +180,42 @@ def cpu_baseline(arch, steps_total, views, res, B):
     t_dec = t_step * (734.0 + 20.0) / (2 * 613.0)
     per_sample = steps_total * t_step + t_dec + views * t_view
     return {"value": round(1.0 / per_sample, 6), "unit": "3D samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads): %d timed EulerEDM+CFG step(s) at B=1 "
+            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads = all host cores): %d timed EulerEDM+CFG step(s) at B=1 "
                       "(%.2f s/step) x %d, VAE decode scaled by FLOPs (%.2f s), 1 view at %d^2 scaled to %d^2 "
                       "(%.2f s/view) x %d views; wall %.0f s" % (cores, n_timed, t_step, steps_total, t_dec, rr, res, t_view,
                                                                    views, time.time() - t_all)}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU over RCCL (the same
+    command line the driver uses for N > 1).  Fails loudly when the box has fewer GPUs than requested."""
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this box exposes %d GPU(s); refusing to report a %d-GPU number from fewer devices" % (n, have, n))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def build_i23d(dev, arch, seed=0, fill=True):
+    from ln3diff_amd.dit.dit_i23d import DiT_models as I23D
+    from ln3diff_amd.synth import fill_module_random_
+    dit = I23D[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=1024, roll_out=True,
+                     pooling_ctx_dim=768).to(dev)
+    if fill:
+        fill_module_random_(dit, seed, dev)
+    return dit
 
 
 def main():
@@ -182,51 +223,73 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE config 2: batch 8)")
-    ap.add_argument("--sample-steps", type=int, default=250)
-    ap.add_argument("--views", type=int, default=8)
-    ap.add_argument("--res", type=int, default=128)
-    ap.add_argument("--arch", default="DiT-L/2")
+    ap.add_argument("--workload", default="t23d", choices=["t23d", "i23d"],
+                    help="t23d = BASELINE configs[1] (the metric's config); i23d = configs[2]")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (t23d: 8, i23d: 32)")
+    ap.add_argument("--sample-steps", type=int, default=None, help="t23d: 250 EulerEDM steps; i23d: num_steps 50 = 49 Euler steps")
+    ap.add_argument("--views", type=int, default=None, help="cameras per sample: 40 (T23D video, train_util_diffusion.py:289) / 24 (I23D, flow_matching_trainer.py:637)")
+    ap.add_argument("--res", type=int, default=256, help="render resolution (the metric: 256^2)")
+    ap.add_argument("--arch", default=None)
     ap.add_argument("--dec-arch", default="DiT2-L/2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
     args = ap.parse_args()
+    i23d = args.workload == "i23d"
+    args.batch = args.batch or (32 if i23d else 8)
+    args.sample_steps = args.sample_steps or (50 if i23d else 250)
+    args.views = args.views or (24 if i23d else 40)
+    args.arch = args.arch or ("DiT-PixArt-L/2" if i23d else "DiT-L/2")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     from ln3diff_amd import parallel
-    from ln3diff_amd.pipeline import T23DPipeline
+    from ln3diff_amd.pipeline import T23DPipeline, FlowMatchingEngine, render_video_given_triplane
     from ln3diff_amd.synth import orbit_cameras
     rank, local_rank, world = parallel.setup_dist()
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
     # rank 0 creates the weights, every rank receives them by ONE flat RCCL broadcast per dtype
-    dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0))
+    if i23d:
+        _, dec = build_models(dev, "DiT-B/2", args.dec_arch, fill=(rank == 0))
+        dit = build_i23d(dev, args.arch, fill=(rank == 0))
+    else:
+        dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0))
     if world > 1:
         parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] +
                                 [b for b in dec.buffers()], src=0)
-    pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
-
     B, Bt = args.batch, args.batch * world
-    g = torch.Generator(device=dev).manual_seed(41)            # global seed, full batch, then sliced per rank
+    g = torch.Generator(device=dev).manual_seed(42 if i23d else 41)            # global seed, full batch, then sliced per rank
     z_all = torch.randn(Bt, 12, 32, 32, device=dev, generator=g)
-    c_all = torch.randn(Bt, 77, 768, device=dev, generator=g)
     lo, hi = parallel.shard_range(Bt, rank, world)
-    cond = {'crossattn': c_all[lo:hi].contiguous()}
-    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
     cams = orbit_cameras(args.views).to(dev)
+    if i23d:
+        eng = FlowMatchingEngine(dit, dec)
+        c_all = {'crossattn': torch.randn(Bt, 256, 2048, device=dev, generator=g), 'vector': torch.randn(Bt, 768, device=dev, generator=g)}
+        cond = {k: v[lo:hi].contiguous() for k, v in c_all.items()}
 
-    def one_step():
-        latent, img = pipe(z_all[lo:hi].clone(), cond, uc, cams, args.res)
-        lat_all = parallel.all_gather_cat(latent)
-        return lat_all, img
+        def one_step():
+            latent = eng.sample(cond, None, batch_size=hi - lo, cfg_scale=4.0, num_steps=args.sample_steps, zs=z_all[lo:hi].clone())
+            img = render_video_given_triplane(latent.clone(), eng.rec_model, cams, eng.triplane_scaling_divider, resolution=args.res)
+            return parallel.all_gather_cat(latent), img
+    else:
+        c_all = torch.randn(Bt, 77, 768, device=dev, generator=g)
+        cond = {'crossattn': c_all[lo:hi].contiguous()}
+        uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+        pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
+
+        def one_step():
+            latent, img = pipe(z_all[lo:hi].clone(), cond, uc, cams, args.res)
+            return parallel.all_gather_cat(latent), img
 
     for _ in range(args.warmup):
         out = one_step()
     # dominant-kernel timing INSIDE the timed region: HIP events on the launch stream around the MLP fc1 GEMM of the middle
-    # layer, every denoise step (an event pair costs ~1 us of stream time per 14 ms step)
+    # layer, every denoise step (an event pair costs ~1 us of stream time per 12 ms step)
     if rank == 0 and not args.no_probes:
         dit._fc1_probe = {'layer': dit.depth // 2, 'events': [], 'max': 4096}
     torch.cuda.synchronize()
@@ -243,22 +306,30 @@ def main():
     ok = bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]['image_raw']).all())
 
     if rank == 0:
+        if i23d:
+            wl = ("BASELINE configs[2]: %s image-cond I23D, flow-matching ODE euler num_steps %d (= %d network evaluations per "
+                  "sample, each on the CFG-doubled batch), CFG 4.0, batch %d per GPU, VAE decode %s + conv decoder, %d views @ %d^2 "
+                  "(64+64 samples/ray)" % (args.arch, args.sample_steps, args.sample_steps - 1, B, args.dec_arch, args.views, args.res))
+            metric = "3D samples/sec (50-step flow-matching DiT-PixArt-L/2 + triplane decode + 256^2 render)"
+        else:
+            wl = ("BASELINE configs[1]: %s text-cond T23D, EulerEDM/LegacyDDPM-sigma %d steps, CFG 6.5 (network batch 2B), batch %d "
+                  "per GPU, VAE decode %s + conv decoder, %d views @ %d^2 (64+64 samples/ray)"
+                  % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res))
+            metric = "3D samples/sec (250-step DiT-L/2 + 256^2 triplane render)"
         rec = {
-            "metric": "3D samples/sec (250-step DiT-L/2 + triplane decode + render)", "value": round(Bt * args.steps / dt, 5),
+            "metric": metric, "value": round(Bt * args.steps / dt, 5),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %s text-cond T23D, EulerEDM/LegacyDDPM-sigma %d steps, CFG 6.5 "
-                                   "(network batch 2B), batch %d per GPU, VAE decode %s + conv decoder, %d views @ %d^2 "
-                                   "(64+64 samples/ray)" % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res),
-                       "global_batch": Bt, "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
+            "config": {"workload": wl, "global_batch": Bt, "views": args.views, "res": args.res,
+                       "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
             "finite": ok,
         }
         if not args.no_probes:
             D = dit.embed_dim
-            ev = dit._fc1_probe['events']
+            ev = dit._fc1_probe['events'] if getattr(dit, '_fc1_probe', None) else []
             dit._fc1_probe = None
-            rec["roofline"] = roofline_probe(dev, 2 * B, D)
+            rec["roofline"] = roofline_probe(dev, 2 * B, D, tokens=768)
             if ev:
                 us = sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3
                 r = rec["roofline"]
@@ -267,9 +338,9 @@ def main():
                 r["launches_timed"] = len(ev)
                 r["achieved"] = round(r["algorithmic_flop_per_launch"] / (us * 1e-6) / 1e12, 1)
                 r["frac"] = round(r["achieved"] / r["peak"], 4)
-            rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 768, D // dit.num_heads)
+            rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 1024 if i23d else 768, D // dit.num_heads, Nq=768)
             rec["roofline_raymarch"] = render_probe(dev, dec)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not i23d:
             rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B)
         print(json.dumps(rec), flush=True)
     parallel.barrier()

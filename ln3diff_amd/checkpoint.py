@@ -9,6 +9,8 @@ Files: `.safetensors` (safetensors.torch.load_file) or torch pickles of a flat s
 """
 import torch
 
+from . import _cache
+
 
 def read_state_dict(path):
     if str(path).endswith(".safetensors"):
@@ -41,6 +43,7 @@ def load_into(module, sd, prefixes=("",), strict=True):
         raise RuntimeError(f"checkpoint does not match the model: {len(missing)} missing (e.g. {missing[:4]}), "
                            f"{len(bad)} shape mismatches (e.g. {bad[:2]})")
     module.load_state_dict(out, strict=strict and not missing)
+    _cache.bump()
     return used
 
 

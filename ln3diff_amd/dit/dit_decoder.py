@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import _cache
 from .dit_models_xformers import (DiTBlock, Workspace, bf16, f32, get_2d_sincos_pos_embed, self_attention_hip,
                                   pad_head_columns)
 
@@ -31,13 +32,14 @@ class DiT2(nn.Module):
         pe = get_2d_sincos_pos_embed(hidden_size, (3 * 16, 16)).reshape(3 * 256, hidden_size)   # vit_triplane.py:333-343
         self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
         self._packed = None
+        _cache.watch(self)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        _cache.bump()
         return super()._apply(fn, *a, **k)
 
     def pack(self, device):
-        if self._packed is not None and self._packed['device'] == device:
+        if _cache.fresh(self._packed, device):
             return self._packed
         P = {'device': device, 'pos': f32(self.pos_embed[0], device), 'blocks': []}
         for b in self.blocks:
@@ -47,7 +49,7 @@ class DiT2(nn.Module):
                  'fc1_w': bf16(b.mlp.mlp[0].weight, device), 'fc1_b': f32(b.mlp.mlp[1].bias, device),
                  'fc2_w': bf16(b.mlp.mlp[2].weight, device), 'fc2_b': f32(b.mlp.mlp[3].bias, device)}
             P['blocks'].append(q)
-        self._packed = P
+        self._packed = _cache.stamp(P)
         return P
 
     @torch.no_grad()

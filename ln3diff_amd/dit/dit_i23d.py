@@ -12,7 +12,7 @@ DINO projection, normed CLIP tokens, every block's cross K / V^T) is computed on
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
                                   self_attention_hip, pad_head_columns)
 from .dit_trilatent import DiT, DiT_TriLatent
@@ -40,7 +40,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         return self.dino_proj
 
     def _ensure_packed(self, device):
-        if self._packed is not None and self._packed['device'] == device:
+        if _cache.fresh(self._packed, device):
             return
         from .dit_models_xformers import Workspace
         D = self.embed_dim
@@ -79,7 +79,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P['fin_w'], P['fin_b'] = f32(self.final_layer.linear.weight, device), f32(self.final_layer.linear.bias, device)
         P['fin_sst'] = f32(self.final_layer.scale_shift_table, device)          # [2, D]
         P['zeros'] = torch.zeros(max(D, self.pooling_ctx_dim), device=device)
-        self._packed = P
+        self._packed = _cache.stamp(P)
         self._ws = Workspace(device)
 
     def _cls_token(self, vec):
@@ -191,6 +191,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         oc = ws.get('oc', (M, H * 64), torch.bfloat16)
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
         ld = 6 * D
+        probe = getattr(self, '_fc1_probe', None)
         for i, q in enumerate(P['blocks']):
             mi = mod[i]
             ops.norm_modulate(xt, ha, M, D, kind=1, eps=1e-5, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
@@ -203,7 +204,14 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
             ops.norm_modulate(xt, hb, M, D, kind=1, eps=1e-5, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],
                               mod_rows=N, mod_ld=ld)
-            ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+            if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # bench.py measurement hook
+                e0.record()
+                ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+                e1.record()
+                probe['events'].append((e0, e1))
+            else:
+                ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=mi[:, 5 * D:], gate_rows=N, gate_ld=ld)
         out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)
         ops.final_layer(xt, tsum, tsum, D, P['fin_sst'][0], P['fin_sst'][1], P['fin_w'], P['fin_b'], out, Bn,

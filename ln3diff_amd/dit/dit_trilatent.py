@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from .dit_models_xformers import (CaptionEmbedder, DiTBlock, FinalLayer, PatchEmbed, T2IFinalLayer,  # noqa: F401
                                   TextCondDiTBlock, TimestepEmbedder, Workspace, bf16, f32,
                                   get_2d_sincos_pos_embed, self_attention_hip, pad_head_columns)
@@ -52,6 +52,7 @@ class DiT(nn.Module):
         self.final_layer = final_layer_blk(hidden_size, patch_size, self.out_channels)
         self.initialize_weights()
         self._packed = None
+        _cache.watch(self)
         self._ws = None
 
     def initialize_weights(self):
@@ -78,11 +79,11 @@ class DiT(nn.Module):
 
     # any parameter change invalidates the packed device copies
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        _cache.bump()
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        _cache.bump()
         return super()._apply(fn, *a, **k)
 
     def flat_weights(self):
@@ -122,10 +123,10 @@ class DiT_TriLatent(DiT):
 
     # ------------------------------------------------------------------ packing
     def _ensure_packed(self, device):
-        if self._packed is not None and self._packed['device'] == device:
+        if _cache.fresh(self._packed, device):
             return
         D = self.embed_dim
-        P = {'device': device}
+        P = _cache.stamp({'device': device})
         P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
         P['pe_b'] = f32(self.x_embedder.proj.bias, device)
         P['pos'] = f32(self.pos_embed[0], device)

@@ -38,24 +38,41 @@ def rotation_matrix_x(deg):
     return np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]], dtype=np.float32)
 
 
+def write_obj(path, v, f, c):
+    """Wavefront .obj with per-vertex colours (what trimesh.Trimesh(vertex_colors=...).export(path, 'obj') writes)."""
+    with open(path, 'w') as fh:
+        for i in range(v.shape[0]):
+            fh.write('v %.6f %.6f %.6f %.4f %.4f %.4f\n' % (v[i, 0], v[i, 1], v[i, 2], c[i, 0], c[i, 1], c[i, 2]))
+        for t in f:
+            fh.write('f %d %d %d\n' % (t[0] + 1, t[1] + 1, t[2] + 1))
+
+
+@torch.no_grad()
+def mesh_from_grid(decoder, dec_out, sigma, grid_size, thr=10.0, sample_index=0, path=None):
+    """nsr/train_util_diffusion.py:221-244: iso-surface of the sigma grid at `thr`, vertices mapped to the +-0.45 box, coloured
+    by re-querying the tri-plane at the vertices (forward_points), rotated -90 degrees about x.
+    Returns (verts [Nv,3] float32 numpy, faces [Nf,3] int64 numpy, colors [Nv,3] uint8 numpy); writes `path` when given."""
+    sigma = sigma.reshape(grid_size, grid_size, grid_size)
+    verts, faces = extract_isosurface(sigma, thr)
+    vtx = (verts / (grid_size - 1) * 2 - 1) * 0.45                       # g-objaverse scale
+    pcl = dec_out.get('planes_channel_last')
+    if pcl is None:
+        from .nsr.triplane import Triplane
+        pcl = Triplane.to_channel_last(dec_out['latent_after_vit'])
+    pcl = pcl[sample_index:sample_index + 1]
+    col = decoder.forward_points(pcl, vtx[None])['rgb'][0] if vtx.shape[0] else vtx
+    colors = (col.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
+    v = (rotation_matrix_x(-90) @ vtx.cpu().numpy().T).T.astype(np.float32)
+    f = faces.cpu().numpy()
+    if path:
+        write_obj(path, v, f, colors.astype(np.float32) / 255.0)
+    return v, f, colors
+
+
 @torch.no_grad()
 def export_mesh(decoder, dec_out, path, grid_size=192, thr=10.0, sample_index=0):
     """decoder: the VAE decoder module; dec_out: its vit_decode_postprocess dict.  Writes `path` (.obj)."""
     pcl = dec_out['planes_channel_last'][sample_index:sample_index + 1]
     grid = decoder.triplane_decode_grid({'planes_channel_last': pcl}, grid_size)
-    verts, faces = extract_isosurface(grid['sigma'][0, ..., 0], thr)
-    vtx = verts / (grid_size - 1) * 2 - 1
-    vtx = vtx * 0.45
-    if vtx.shape[0]:
-        col = decoder.forward_points(pcl, vtx[None])['rgb'][0].clamp(0, 1)
-    else:
-        col = vtx
-    v = (rotation_matrix_x(-90) @ vtx.cpu().numpy().T).T
-    c = col.cpu().numpy()
-    f = faces.cpu().numpy() + 1
-    with open(path, 'w') as fh:
-        for i in range(v.shape[0]):
-            fh.write('v %.6f %.6f %.6f %.4f %.4f %.4f\n' % (v[i, 0], v[i, 1], v[i, 2], c[i, 0], c[i, 1], c[i, 2]))
-        for t in f:
-            fh.write('f %d %d %d\n' % (t[0], t[1], t[2]))
+    v, f, _ = mesh_from_grid(decoder, {'planes_channel_last': pcl}, grid['sigma'][0], grid_size, thr, 0, path)
     return v.shape[0], f.shape[0]

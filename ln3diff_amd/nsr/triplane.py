@@ -11,8 +11,9 @@ or its sort/gather intermediates is ever materialised.
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from .._lib import RENDER_SCRATCH_FLOATS
+from .volumetric_rendering.renderer import ImportanceRenderer, check_rendering_options, draw_render_noise  # noqa: F401
 
 
 class FullyConnectedLayer(nn.Module):      # nsr/networks_stylegan2.py:122-157 (container; gain applied in-kernel)
@@ -34,22 +35,14 @@ class OSGDecoder(nn.Module):               # nsr/triplane.py:339-372
                                  FullyConnectedLayer(self.hidden_dim, 1 + self.decoder_output_dim))
 
 
+# nsr/script_util.py:433-465,761-798 (probe of rendering_options_defaults).  return_sampling_details_flag is
+# True in the reference's preset; it defaults to False here because the sampling drivers never read `shape_synthesized` and the
+# per-sample tensors cost 100 MB of HBM writes per 256^2 view - set it to get them.
 OBJAVERSE_RENDERING_KWARGS = dict(
     depth_resolution=64, depth_resolution_importance=64, ray_start='auto', ray_end='auto', box_warp=0.9,
     white_back=True, sampler_bbox_min=-0.45, sampler_bbox_max=0.45, filter_out_of_bbox=True,
-    clamp_mode='softplus', disparity_space_sampling=False, PatchRaySampler=True, decoder_lr_mul=1)
-
-
-def draw_render_noise(V, M, S=64, generator=None, device='cpu'):
-    """The reference's RNG consumption per Triplane.forward, as logical tensors:
-    coarse jitter = rand_like on a [S,V,M,1]-strided tensor, then fine uniforms rand(V*M, S)."""
-    if device == 'cpu' or str(device) == 'cpu':
-        j = torch.rand(S, V, M, 1, generator=generator).permute(1, 2, 0, 3).reshape(V, M, S).contiguous()
-        u = torch.rand(V * M, S, generator=generator)
-    else:
-        j = torch.rand(V, M, S, device=device, generator=generator)
-        u = torch.rand(V * M, S, device=device, generator=generator)
-    return j, u
+    clamp_mode='softplus', disparity_space_sampling=False, PatchRaySampler=True, decoder_lr_mul=1,
+    return_sampling_details_flag=False, image_resolution=256, z_near=1.05, z_far=2.45, radius_range=[1.5, 2])
 
 
 class Triplane(nn.Module):
@@ -57,24 +50,22 @@ class Triplane(nn.Module):
                  rendering_kwargs=None, decoder_in_chans=32, decoder_output_dim=3, **_):
         super().__init__()
         self.rendering_kwargs = dict(OBJAVERSE_RENDERING_KWARGS if rendering_kwargs is None else rendering_kwargs)
-        rk = self.rendering_kwargs
-        assert rk['depth_resolution'] == 64 and rk['depth_resolution_importance'] == 64
-        assert rk['ray_start'] == rk['ray_end'] == 'auto' and rk.get('filter_out_of_bbox', False)
+        check_rendering_options(self.rendering_kwargs)
+        self.renderer = ImportanceRenderer()             # the explicit-ray seam (nsr/triplane.py:470 in the reference)
         self.neural_rendering_resolution = img_resolution
         self.decoder_in_chans = decoder_in_chans
         self.decoder = OSGDecoder(decoder_in_chans, {'decoder_lr_mul': 1, 'decoder_output_dim': decoder_output_dim})
         self._dec = None
+        self._dec_epoch = -1
+        _cache.watch(self)
 
     def _apply(self, fn, *a, **k):
-        self._dec = None
+        _cache.bump()
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
-        self._dec = None
-        return super().load_state_dict(*a, **k)
-
     def _decoder_dev(self, dev):
-        if self._dec is None or self._dec[0].device != dev:
+        if self._dec is None or self._dec[0].device != dev or self._dec_epoch != _cache.EPOCH[0]:
+            self._dec_epoch = _cache.EPOCH[0]
             n = self.decoder.net
             self._dec = tuple(t.detach().to(dev, torch.float32).contiguous()
                               for t in (n[0].weight, n[0].bias, n[2].weight, n[2].bias))
@@ -113,18 +104,27 @@ class Triplane(nn.Module):
         wsum = torch.empty(V, 1, res, res, device=dev)
         lim = torch.empty(V * M * 2, device=dev)
         scal = torch.empty(RENDER_SCRATCH_FLOATS, device=dev)
-        cs = torch.empty(V, M, S, device=dev) if return_debug else None
+        # sampling details (the reference's `shape_synthesized`, nsr/triplane.py:569-573 / renderer.py:196-283): 100 MB per 256^2
+        # view, so only on request - rendering_kwargs['return_sampling_details_flag'] (the reference preset sets it) or return_debug
+        details = bool(rk.get('return_sampling_details_flag', False))
+        cs = torch.empty(V, M, S, device=dev) if (return_debug or details) else None
         fd = torch.empty(V, M, S, device=dev) if return_debug else None
+        fs = torch.empty(V, M, S, device=dev) if details else None
+        cc = torch.empty(V, M, S, 3, device=dev) if details else None
+        fc = torch.empty(V, M, S, 3, device=dev) if details else None
         ops.render_triplane(planes_channel_last, H, W, plane_index.to(dev, torch.int32).contiguous(),
                             c.to(torch.float32).contiguous(), res, self._decoder_dev(dev), jitter, u_fine, rgb, depth,
                             wsum, lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
                             bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=cs,
-                            fine_depths=fd)
+                            fine_depths=fd, fine_sigma=fs, coarse_coords=cc, fine_coords=fc)
         ret = {'feature_image': rgb, 'image_raw': rgb, 'image_depth': depth, 'weights_samples': wsum,
                'image_mask': wsum * (1 + 2 * 0.001) - 0.001,
-               'shape_synthesized': {'image_depth': depth}}
+               'shape_synthesized': {'image_depth': depth, 'depth': depth.reshape(V, M, 1)}}
         if return_debug:
             ret['shape_synthesized'].update(coarse_densities=cs.unsqueeze(-1), fine_depths=fd.unsqueeze(-1))
+        if details:
+            ret['shape_synthesized'].update(coarse_coords=cc, coarse_densities=cs.unsqueeze(-1), fine_coords=fc.reshape(V, M * S, 3),
+                                            fine_densities=fs.unsqueeze(-1))
         return ret
 
     @torch.no_grad()

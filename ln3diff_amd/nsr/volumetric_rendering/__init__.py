@@ -1,0 +1,1 @@
+from .renderer import ImportanceRenderer  # noqa: F401

@@ -13,6 +13,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _cache
+
 
 def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -49,6 +51,7 @@ def broadcast_flat(tensors, src=0):
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
+    _cache.bump()          # in-place parameter writes: packed device copies of the weights are stale now
 
 
 def shard_range(total, rank, world):
@@ -60,11 +63,24 @@ def shard_range(total, rank, world):
 
 
 def all_gather_cat(t):
+    """Concatenate every rank's rows (dim 0).  Shards may be ragged or EMPTY (fewer samples than ranks): the row counts are
+    gathered first, every rank pads to the largest shard, and the padding is dropped after the collective.  All ranks must
+    call it (it is a collective) - also the ones whose shard is empty."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t
-    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(outs, t.contiguous())
-    return torch.cat(outs, 0)
+    world = dist.get_world_size()
+    n_loc = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n_loc) for _ in range(world)]
+    dist.all_gather(counts, n_loc)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n_max == 0:
+        return t
+    pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], 0)
 
 
 def barrier():

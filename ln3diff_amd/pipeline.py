@@ -1,43 +1,118 @@
-"""End-to-end text->3D sampling pipeline on the HIP path (restates the reference drivers
-DiffusionEngineLSGM.sample/eval_cldm (nsr/lsgm/sgm_DiffusionEngine.py:386-480) and
-render_video_given_triplane (nsr/train_util_diffusion.py:177-300)): noise -> EulerEDM x num_steps with CFG
--> latent * triplane_scaling_divider -> VAE decode -> V views per sample through the fused ray-marcher."""
+"""Sampling drivers on the HIP path - restatements of the reference's engine methods:
+
+  DiffusionEngineLSGM.sample / eval_cldm      nsr/lsgm/sgm_DiffusionEngine.py:386-480   -> T23DPipeline
+  FlowMatchingEngine.sample / eval_cldm /
+      eval_i23d_and_export                     nsr/lsgm/flow_matching_trainer.py:510-760 -> FlowMatchingEngine (alias I23DPipeline)
+  TrainLoop.render_video_given_triplane        nsr/train_util_diffusion.py:177-300       -> render_video_given_triplane
+
+What is kept: seeding (th.manual_seed(41) / seed 42 before the z draw), z shape, `repeat_interleave` of one condition over
+num_samples, the unconditional branch = ZERO embeddings (`force_uc_zero_embeddings`), the CFG concat order (sgm: [uc, c];
+flow matching: [c, uc]), `planes *= triplane_scaling_divider`, the AE behaviour strings, 40 cameras for the T23D video and
+`camera[:24]` for the I23D one, marching at threshold 10 on a 192^3 grid scaled to +-0.45 and rotated -90 deg about x.
+What is dropped: video encoding / logging, `th.cuda.empty_cache()` calls, and the one-camera-per-call loop (all views of a
+sample are one renderer launch; per-view results do not depend on the batching).
+"""
 import torch
 
 from .sgm.sampling import DiscreteDenoiser, EulerEDMSampler, VanillaCFG
 
-TRIPLANE_SCALING_DIVIDER = 0.96806      # nsr/train_util_diffusion.py:188
+TRIPLANE_SCALING_DIVIDER = 0.96806      # the released Objaverse runs (shell_scripts/final_release/inference/*.sh); a CLI flag there
+
+
+@torch.no_grad()
+def render_video_given_triplane(planes, rec_model, cams, triplane_scaling_divider=TRIPLANE_SCALING_DIVIDER, latent_name='latent_normalized_2Ddiffusion',
+                                export_mesh=False, mesh_size=192, mesh_thres=10, mesh_path=None, resolution=None, jitter=None, u_fine=None):
+    """planes: sampled latent [B, 12, 32, 32] (scaled IN PLACE like the reference, :188); rec_model: `AE`; cams [V, 25] rendered
+    for every sample.  Returns {'latent_after_vit' (if produced), 'image_raw' [B,V,3,R,R], 'image_depth', 'weights_samples',
+    'image_mask', 'mesh': [(verts, faces, colors)] when export_mesh}."""
+    planes *= triplane_scaling_divider
+    ddpm_latent = {latent_name: planes}
+    ddpm_latent.update(rec_model(latent=ddpm_latent, behaviour='decode_after_vae_no_render'))
+    out = {}
+    if export_mesh:
+        from .mesh import mesh_from_grid
+        grid_out = rec_model(latent=ddpm_latent, grid_size=mesh_size, behaviour='triplane_decode_grid')
+        out['mesh'] = [mesh_from_grid(rec_model.decoder, ddpm_latent, grid_out['sigma'][i], mesh_size, mesh_thres, sample_index=i,
+                                      path=(mesh_path.format(i) if mesh_path else None)) for i in range(planes.shape[0])]
+    B, V = planes.shape[0], cams.shape[0]
+    kw = {}
+    if resolution is not None:
+        kw['neural_rendering_resolution'] = resolution
+    pcl = ddpm_latent.get('planes_channel_last')
+    if pcl is not None:
+        kw['plane_index'] = torch.arange(B, device=planes.device, dtype=torch.int32).repeat_interleave(V)
+    pred = rec_model(img=None, c=cams.repeat(B, 1), latent=ddpm_latent, behaviour='triplane_dec', jitter=jitter, u_fine=u_fine, **kw)
+    for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
+        out[k] = pred[k].view(B, V, *pred[k].shape[1:])
+    if 'latent_after_vit' in ddpm_latent:
+        out['latent_after_vit'] = ddpm_latent['latent_after_vit']
+    out['planes_channel_last'] = pcl
+    return out
+
+
+def _zero_uc(cond):
+    """GeneralConditioner.get_unconditional_conditioning(..., force_uc_zero_embeddings=[cond_key]) (encoders/modules.py:161-163,
+    sgm_DiffusionEngine.py:448-452): every tensor of the unconditional branch is zeros."""
+    return {k: torch.zeros_like(v) for k, v in cond.items()}
 
 
 class T23DPipeline:
-    def __init__(self, dit, decoder, num_steps=250, cfg_scale=6.5, conditioner=None):
+    """Text -> 3D: EulerEDM (LegacyDDPM sigmas) + VanillaCFG over DiT_TriLatent, then decode + render."""
+
+    def __init__(self, dit, decoder, num_steps=250, cfg_scale=6.5, conditioner=None, triplane_scaling_divider=TRIPLANE_SCALING_DIVIDER,
+                 img_size=128):
+        from .nsr.script_util import AE
         self.dit, self.decoder, self.conditioner = dit, decoder, conditioner
+        self.rec_model = decoder if isinstance(decoder, AE) else AE(None, decoder, img_size)
         self.sampler = EulerEDMSampler(num_steps=num_steps, guider=VanillaCFG(cfg_scale))
         self.denoiser = DiscreteDenoiser()
+        self.triplane_scaling_divider = triplane_scaling_divider
 
     @torch.no_grad()
     def encode_prompts(self, captions, uc_captions=None):
-        """GeneralConditioner semantics for the T23D config (sgm/modules/encoders/modules.py:80-191,
-        sgm/configs/txt2img-clipl-compat.yaml): one FrozenCLIPEmbedder on key 'caption' ->
-        cond = {'crossattn': last_hidden_state, 'vector': pooled}; uc = the same for the legacy ucg value "" (or the ids
-        passed in uc_captions).  captions: list of strings (needs the BPE vocabulary) or int token ids [B, 77]."""
+        """GeneralConditioner semantics for the T23D config (sgm/modules/encoders/modules.py:80-191): one FrozenCLIPEmbedder on key
+        'caption' -> cond = {'crossattn': last_hidden_state, 'vector': pooled}.  The unconditional branch is ZEROS (what the
+        sampling driver asks for with force_uc_zero_embeddings, sgm_DiffusionEngine.py:448-452); pass uc_captions only to get the
+        legacy "encode the empty prompt" behaviour.  captions: list of strings or int token ids [B, 77]."""
         assert self.conditioner is not None, "construct the pipeline with conditioner=FrozenCLIPEmbedder(...)"
         z, pooled = self.conditioner(captions)
-        B = z.shape[0]
+        cond = {'crossattn': z, 'vector': pooled}
         if uc_captions is None:
-            uc_captions = [""] * B
+            return cond, _zero_uc(cond)
         zu, pu = self.conditioner(uc_captions)
-        return {'crossattn': z, 'vector': pooled}, {'crossattn': zu.clone(), 'vector': pu.clone()}
+        return cond, {'crossattn': zu.clone(), 'vector': pu.clone()}
 
     @torch.no_grad()
-    def sample_latent(self, z, cond, uc):
-        return self.sampler(self.denoiser, self.dit, z, cond, uc)
+    def sample_latent(self, z, cond, uc=None):
+        return self.sampler(self.denoiser, self.dit, z, cond, _zero_uc(cond) if uc is None else uc)
+
+    # DiffusionEngineLSGM.sample (:386-407): z ~ randn(seed), shape [N, 3*C, S, S]
+    @torch.no_grad()
+    def sample(self, cond, uc=None, batch_size=1, shape=None, seed=41, device=None):
+        device = device or cond['crossattn'].device
+        shape = shape or (3 * self.dit.in_channels if self.dit.roll_out else self.dit.in_channels, 32, 32)
+        torch.manual_seed(seed)
+        z = torch.randn(batch_size, *shape).to(device)
+        return self.sample_latent(z, cond, uc)
+
+    # DiffusionEngineLSGM.eval_cldm (:410-480): one condition x num_samples, then the video of every sample
+    @torch.no_grad()
+    def eval_cldm(self, cond, cams, num_samples=1, resolution=None, export_mesh=False, seed=41, **render_kw):
+        assert cond['crossattn'].shape[0] == 1
+        c = {k: v.repeat_interleave(num_samples, 0) for k, v in cond.items()}
+        latent = self.sample(c, None, batch_size=num_samples, seed=seed)
+        return latent, self.render_video_given_triplane(latent.clone(), cams[:40], resolution=resolution, export_mesh=export_mesh, **render_kw)
+
+    @torch.no_grad()
+    def render_video_given_triplane(self, planes, cams, **kw):
+        return render_video_given_triplane(planes, self.rec_model, cams, self.triplane_scaling_divider, **kw)
 
     @torch.no_grad()
     def decode(self, latent, want_nchw=False):
-        lat = latent * TRIPLANE_SCALING_DIVIDER
-        tok = self.decoder.vit_decode_backbone({'latent_normalized_2Ddiffusion': lat}, 128)
-        return self.decoder.vit_decode_postprocess(tok, {}, want_nchw=want_nchw)
+        lat = latent * self.triplane_scaling_divider
+        dec = self.rec_model.decoder
+        tok = dec.vit_decode_backbone({'latent_normalized_2Ddiffusion': lat}, 128)
+        return dec.vit_decode_postprocess(tok, {}, want_nchw=want_nchw)
 
     @torch.no_grad()
     def render(self, dec_out, cams, res, jitter=None, u_fine=None):
@@ -46,8 +121,8 @@ class T23DPipeline:
         B, V = pcl.shape[0], cams.shape[0]
         c = cams.repeat(B, 1)
         idx = torch.arange(B, device=pcl.device, dtype=torch.int32).repeat_interleave(V)
-        out = self.decoder.triplane_decoder(c=c, planes_channel_last=pcl, plane_index=idx,
-                                            neural_rendering_resolution=res, jitter=jitter, u_fine=u_fine)
+        out = self.rec_model.decoder.triplane_decoder(c=c, planes_channel_last=pcl, plane_index=idx,
+                                                      neural_rendering_resolution=res, jitter=jitter, u_fine=u_fine)
         return {k: (v.view(B, V, *v.shape[1:]) if torch.is_tensor(v) else v) for k, v in out.items()
                 if k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask')}
 
@@ -57,3 +132,59 @@ class T23DPipeline:
         dec = self.decode(latent)
         img = self.render(dec, cams, res)
         return latent, img
+
+
+class FlowMatchingEngine:
+    """Image -> 3D (and the flow-matching T23D variant): transport ODE sampler over `ddpm_model.forward_with_cfg`."""
+
+    def __init__(self, ddpm_model, decoder, conditioner=None, triplane_scaling_divider=TRIPLANE_SCALING_DIVIDER, img_size=128,
+                 path_type='Linear', prediction='velocity', snr_type='lognorm', sampling_method='euler'):
+        from .nsr.script_util import AE
+        from .transport import Sampler, create_transport
+        self.ddpm_model, self.conditioner = ddpm_model, conditioner
+        self.rec_model = decoder if isinstance(decoder, AE) else AE(None, decoder, img_size)
+        self.transport = create_transport(path_type=path_type, prediction=prediction, snr_type=snr_type)
+        self.transport_sampler = Sampler(self.transport)
+        self.sampling_method = sampling_method
+        self.triplane_scaling_divider = triplane_scaling_divider
+
+    # FlowMatchingEngine.sample (:510-552)
+    @torch.no_grad()
+    def sample(self, cond, uc=None, batch_size=16, shape=None, use_cfg=True, cfg_scale=4.0, num_steps=250, seed=42, zs=None, **kwargs):
+        assert use_cfg
+        uc = _zero_uc(cond) if uc is None else uc
+        dev = cond['crossattn'].device
+        shape = shape or (3 * self.ddpm_model.in_channels if self.ddpm_model.roll_out else self.ddpm_model.in_channels, 32, 32)
+        if zs is None:
+            torch.manual_seed(seed)
+            zs = torch.randn(batch_size, *shape).to(dev)
+        c_out = {k: torch.cat((cond[k], uc[k]), 0) for k in cond if k in ('vector', 'crossattn', 'concat')}     # [c, uc]
+        zs = torch.cat([zs, zs], 0)
+        fn = self.transport_sampler.sample_ode(sampling_method=self.sampling_method, num_steps=num_steps)
+        cache = self.ddpm_model.prepare_context(c_out) if hasattr(self.ddpm_model, 'prepare_context') else None
+        kw = dict(context_cache=cache) if cache is not None else dict(context=c_out)
+        samples = fn(zs, self.ddpm_model.forward_with_cfg, return_trajectory=False, cfg_scale=cfg_scale, **kw)[-1]
+        return samples.chunk(2, dim=0)[0].contiguous()                                                            # drop the null half
+
+    # FlowMatchingEngine.eval_cldm (:554-682): one condition x num_samples; camera[:24]
+    @torch.no_grad()
+    def eval_cldm(self, cond, camera, num_samples=1, unconditional_guidance_scale=4.0, num_steps=250, seed=42, export_mesh=False,
+                  resolution=None, **render_kw):
+        assert cond['crossattn'].shape[0] == 1
+        c = {k: v.repeat_interleave(num_samples, 0) for k, v in cond.items()}
+        samples = self.sample(c, None, batch_size=num_samples, cfg_scale=unconditional_guidance_scale, num_steps=num_steps, seed=seed)
+        return samples, render_video_given_triplane(samples.clone(), self.rec_model, camera[:24], self.triplane_scaling_divider,
+                                                    export_mesh=export_mesh, resolution=resolution, **render_kw)
+
+    # FlowMatchingEngine.eval_i23d_and_export (:684-760): image -> conditioner -> sample -> mesh + video
+    @torch.no_grad()
+    def eval_i23d_and_export(self, inp_img, camera, num_steps=250, seed=42, mesh_size=192, mesh_thres=10, unconditional_guidance_scale=4.0,
+                             num_samples=1, export_mesh=True, resolution=None, mesh_path=None):
+        assert self.conditioner is not None, "construct the engine with conditioner=I23DConditioner(...)"
+        cond = self.conditioner(inp_img)
+        samples, out = self.eval_cldm(cond, camera, num_samples, unconditional_guidance_scale, num_steps, seed, export_mesh,
+                                      resolution, mesh_size=mesh_size, mesh_thres=mesh_thres, mesh_path=mesh_path)
+        return samples, out
+
+
+I23DPipeline = FlowMatchingEngine

@@ -14,7 +14,7 @@ merges files): `forward(text)` uses transformers.CLIPTokenizer when those files 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from ..dit.dit_models_xformers import Workspace, bf16, f32
 
 
@@ -84,6 +84,7 @@ class FrozenCLIPEmbedder(nn.Module):
         self.transformer = CLIPTextModel(**model_kwargs)
         self._tok = None
         self._packed = None
+        _cache.watch(self)
         if freeze:
             self.freeze()
 
@@ -111,7 +112,7 @@ class FrozenCLIPEmbedder(nn.Module):
 
     # ------------------------------------------------------------------ packing
     def _ensure_packed(self, dev):
-        if self._packed is not None and self._packed['dev'] == dev:
+        if _cache.fresh(self._packed, dev, 'dev'):
             return
         tm = self.transformer.text_model
         P = {'dev': dev, 'tok': f32(tm.embeddings.token_embedding.weight, dev), 'pos': f32(tm.embeddings.position_embedding.weight, dev),
@@ -128,7 +129,7 @@ class FrozenCLIPEmbedder(nn.Module):
                 'fc2_w': bf16(l.mlp.fc2.weight, dev), 'fc2_b': f32(l.mlp.fc2.bias, dev)})
         D = P['tok'].shape[1]
         P['zeros'] = torch.zeros(D, device=dev)
-        self._packed, self._ws = P, Workspace(dev)
+        self._packed, self._ws = _cache.stamp(P), Workspace(dev)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

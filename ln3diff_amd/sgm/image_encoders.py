@@ -16,7 +16,7 @@ patch-embedding convolution is a patchify kernel + one GEMM (K = 588 padded to 6
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from ..dit.dit_models_xformers import Workspace, bf16, f32
 
 
@@ -177,6 +177,8 @@ class _ImageEmbedderBase(nn.Module):
         super().__init__()
         self.device = device
         self._runner = None
+        self._epoch = -1
+        _cache.watch(self)
         self.register_buffer("mean", torch.tensor(self.MEAN), persistent=False)
         self.register_buffer("std", torch.tensor(self.STD), persistent=False)
 
@@ -199,8 +201,10 @@ class _ImageEmbedderBase(nn.Module):
             raise RuntimeError("ln3diff_amd image embedders run on the HIP device only (no CPU fallback)")
         if image.dim() == 5:
             image = image.reshape(-1, *image.shape[2:])
-        if self._runner is None or self._runner.dev != image.device:
+        if self._runner is None or self._runner.dev != image.device or self._epoch != _cache.EPOCH[0]:
             self._runner = _ViTRunner(self._spec(), image.device)
+            self._proj_bf = None
+            self._epoch = _cache.EPOCH[0]
         return self._runner(self.preprocess(image.float()))
 
 

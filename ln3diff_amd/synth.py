@@ -55,6 +55,8 @@ def fill_module_random_(module, seed=0, device=None):
             continue
         off, sc = _scale_rule(k, v.shape)
         v.copy_(torch.randn(v.shape, generator=g, device=g.device, dtype=torch.float32).mul_(sc).add_(off))
+    from . import _cache
+    _cache.bump()          # in-place parameter writes: packed device copies of the weights are stale now
     return module
 
 

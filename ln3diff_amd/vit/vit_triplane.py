@@ -14,7 +14,7 @@ produced only when a caller asks for `latent_after_vit`)."""
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, _cache
 from ..dit.dit_decoder import DiT2
 from ..dit.dit_models_xformers import Workspace, bf16, f32
 from ..nsr.triplane import Triplane
@@ -116,18 +116,15 @@ class RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout
         self.rendering_kwargs = triplane_decoder.rendering_kwargs
         self._packed = None
         self._ws = None
+        _cache.watch(self)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        _cache.bump()
         return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
 
     # ------------------------------------------------------------------ packing
     def _ensure_packed(self, dev):
-        if self._packed is not None and self._packed['device'] == dev:
+        if _cache.fresh(self._packed, dev):
             return
         sr = self.superresolution
         P = {'device': dev}
@@ -156,7 +153,7 @@ class RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout
             P['up'].append(q)
         P['norm_out'] = (f32(d.norm_out.weight, dev), f32(d.norm_out.bias, dev))
         P['conv_out'] = _pack_conv3(d.conv_out, dev)
-        self._packed = P
+        self._packed = _cache.stamp(P)
         self._ws = Workspace(dev)
 
     # ------------------------------------------------------------------ conv decoder pieces (channel-last)
@@ -275,6 +272,18 @@ class RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout
             ret = self.triplane_decoder(planes, c, **kwargs)
         ret.update({'latent_after_vit': planes, **vit_decode_out})
         return ret
+
+    @torch.no_grad()
+    def triplane_renderer(self, latent, coordinates, directions=None):
+        """decoder output at explicit points (vit/vit_triplane.py:377-388 -> renderer.run_model): latent = tri-planes
+        [B,96,H,W] / dict, coordinates [B,P,3] -> {'rgb': [B,P,3], 'sigma': [B,P,1]} (directions are unused by OSGDecoder)."""
+        if isinstance(latent, dict):
+            pcl = latent.get('planes_channel_last')
+            if pcl is None:
+                pcl = Triplane.to_channel_last(latent['latent_after_vit'])
+        else:
+            pcl = Triplane.to_channel_last(latent)
+        return self.forward_points(pcl, coordinates)
 
     @torch.no_grad()
     def forward_points(self, planes_channel_last, points, chunk_size=2 ** 16):

@@ -41,6 +41,13 @@ def _worker(rank, world, port, q):
     local = z_all[lo:hi] * 2.0                        # stand-in for "sample my shard"
     gathered = parallel.all_gather_cat(local)
     ok_g = torch.equal(gathered, z_all * 2.0)
+    # 3) ragged and EMPTY shards: totals that do not divide by the world size, and fewer samples than ranks (the gather is a
+    #    collective - every rank calls it, also with zero rows; the entry script's and bench.py's sharding code)
+    for total in (7, 5, 1):
+        zt = torch.randn(total, 12, 4, 4, generator=torch.Generator().manual_seed(41))
+        lo, hi = parallel.shard_range(total, rank, world)
+        got = parallel.all_gather_cat(zt[lo:hi] * 2.0)
+        ok_g = ok_g and got.shape[0] == total and torch.equal(got, zt * 2.0)
     t = parallel.max_over_ranks(1.0 + rank)
     parallel.barrier()
     q.put((rank, ok_b, ok_g, t))
