@@ -198,7 +198,7 @@ int ln3d_axpby(const float* x, float* y, float a, float b, int64_t n, void* stre
  */
 int ln3d_planes_to_channel_last(const float* planes_nchw, float* planes_nhwc, int NP, int C, int H, int W, void* stream);
 int ln3d_planes_to_nchw(const float* planes_nhwc, float* planes_nchw, int NP, int C, int H, int W, void* stream);
-#define LN3D_RENDER_SCRATCH_FLOATS 4096   /* size of ln3d_render_args.scalars */
+#define LN3D_RENDER_SCRATCH_FLOATS 16384  /* size of ln3d_render_args.scalars (64 KB): decoder image + per-call range records */
 
 typedef struct {
   const float* planes; int H, W;        /* channel-last tri-planes                                 */
@@ -228,6 +228,12 @@ typedef struct {
   float* fine_sigma;    /* [V,M,S]   (optional) */
   float* coarse_coords; /* [V,M,S,3] (optional) sample positions of the coarse pass */
   float* fine_coords;   /* [V,M,S,3] (optional) sample positions of the importance pass */
+  /* The reference takes three reductions over everything ONE forward() call renders: the ray-limit fix-up (renderer.py:151-155)
+   * and the depth clamp to [min, max] of all sample depths (ray_marcher.py:57-61).  views_per_call = how many consecutive views
+   * form one such call: 0 (or >= V) = the whole launch is one call (Triplane.forward on a batch); 1 = every view is its own
+   * call (the video drivers render one camera per call, nsr/train_util_diffusion.py:262-283).  At most
+   * (LN3D_RENDER_SCRATCH_FLOATS - 2400) / 8 calls per launch. */
+  int views_per_call;
 } ln3d_render_args;
 /* Triplane.forward -> ImportanceRenderer.forward -> MipRayMarcher2 (nsr/triplane.py:505-750,
  * nsr/volumetric_rendering/renderer.py:133-307, ray_marcher.py:26-68, ray_sampler.py:262-331),
@@ -235,7 +241,7 @@ typedef struct {
 int ln3d_render_triplane(const ln3d_render_args* a, void* stream);
 
 /* triplane_decode_grid / forward_points (vit/vit_triplane.py:2009-2112): points f32 [P,3] -> sigma[P], rgb[P,3].
- * scalars: caller-owned scratch of LN3D_RENDER_SCRATCH_FLOATS floats (the decoder's fragment image is built into it) */
+ * scalars: caller-owned scratch of >= 4096 floats (the decoder's fragment image is built into it) */
 int ln3d_query_points(const float* planes, int H, int W, const float* points, int64_t P,
                       const float* dec_w0, const float* dec_b0, const float* dec_w1, const float* dec_b1,
                       float box_warp, float* sigma, float* rgb, float* scalars, void* stream);
@@ -251,7 +257,10 @@ int ln3d_mesh_emit(const float* sigma, int G, float thr, const int64_t* offsets_
 
 /* ---------------------------------------------------------------- conv decoder pieces (channel-last f32/bf16)
  * GroupNorm(32, eps 1e-6, affine) + optional swish over x f32 [N, HW, C] -> bf16 (ldm model.py:45-51)        */
-int ln3d_groupnorm_swish(const float* x, const float* w, const float* b, void* y_bf16, float* stats_scratch /* [N*groups*2] */,
+#define LN3D_GN_PIXELS_PER_CHUNK 256
+/* stats_scratch: [N*groups*2 * (1 + ceil(HW / LN3D_GN_PIXELS_PER_CHUNK))] floats - the sums, then one partial pair per pixel chunk
+ * (reduced in chunk order: the result is bitwise reproducible) */
+int ln3d_groupnorm_swish(const float* x, const float* w, const float* b, void* y_bf16, float* stats_scratch,
                          int N, int HW, int C, int groups, float eps, int swish, void* stream);
 /* im2col for 3x3 pad 1 convs on channel-last bf16 [N,H,W,C] with optional nearest 2x upsample of the input
  * (ldm model.py:54-70): out bf16 [N*Ho*Wo, Kpad], column = (ky*3+kx)*C + c, zero padded to Kpad             */

@@ -18,7 +18,8 @@ SYMBOLS = [
 ]
 
 EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU, EPI_CROSS_ATTN = range(10)
-RENDER_SCRATCH_FLOATS = 4096
+RENDER_SCRATCH_FLOATS = 16384
+RENDER_MAX_CALLS = (RENDER_SCRATCH_FLOATS - 2392) // 8      # per-call range records after the decoder image (csrc/render.hip)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -50,7 +51,7 @@ class RenderArgs(C.Structure):
                 ("jitter", vp), ("u_fine", vp), ("box_warp", f32), ("bbox_min", f32), ("bbox_max", f32),
                 ("white_back", i32), ("rgb", vp), ("depth", vp), ("wsum", vp), ("ray_limits", vp),
                 ("scalars", vp), ("coarse_sigma", vp), ("fine_depths", vp), ("ray_o", vp), ("ray_d", vp),
-                ("fine_sigma", vp), ("coarse_coords", vp), ("fine_coords", vp)]
+                ("fine_sigma", vp), ("coarse_coords", vp), ("fine_coords", vp), ("views_per_call", i32)]
 
 
 _lib = None
@@ -77,7 +78,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 4
+    assert L.ln3d_abi_version() == 5
     return True
 
 

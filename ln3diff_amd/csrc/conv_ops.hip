@@ -28,9 +28,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, float* st
         ts += sh[0][pp * C + threadIdx.x * cpg + cc];
         tq += sh[1][pp * C + threadIdx.x * cpg + cc];
       }
-    atomicAdd(&stats[((int64_t)n * groups + threadIdx.x) * 2 + 0], ts);
-    atomicAdd(&stats[((int64_t)n * groups + threadIdx.x) * 2 + 1], tq);
+    // per-chunk partial sums; gn_reduce_kernel adds them in chunk order (fp32 atomics here made the planes differ from run to run)
+    float* part = stats + 2 * (int64_t)gridDim.y * groups + (((int64_t)n * gridDim.x + blockIdx.x) * groups + threadIdx.x) * 2;
+    part[0] = ts; part[1] = tq;
   }
+}
+
+__global__ void gn_reduce_kernel(float* stats, int N, int groups, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (n, group)
+  if (i >= N * groups) return;
+  const int n = i / groups, g = i % groups;
+  const float* part = stats + 2 * (int64_t)N * groups + ((int64_t)n * chunks * groups + g) * 2;
+  float ts = 0.f, tq = 0.f;
+  for (int c = 0; c < chunks; ++c) { ts += part[(int64_t)c * groups * 2]; tq += part[(int64_t)c * groups * 2 + 1]; }
+  stats[2 * i] = ts; stats[2 * i + 1] = tq;
 }
 
 __global__ void gn_apply_kernel(const float* x, const float* stats, const float* w, const float* b, bf16_t* y, int64_t total4,
@@ -61,9 +72,10 @@ extern "C" int ln3d_groupnorm_swish(const float* x, const float* w, const float*
                                     int C, int groups, float eps, int swish, void* stream) {
   if (!x || !w || !b || !y || !stats_scratch || C % groups || 256 % C || C % 4) return LN3D_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(stats_scratch, 0, sizeof(float) * 2 * N * groups, s) != hipSuccess) return LN3D_ERR_LAUNCH;
-  const int ppb = 256;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(256), 0, s, x, stats_scratch, HW, C, groups, ppb);
+  const int ppb = LN3D_GN_PIXELS_PER_CHUNK;
+  const int chunks = (HW + ppb - 1) / ppb;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N), dim3(256), 0, s, x, stats_scratch, HW, C, groups, ppb);
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3((N * groups + 255) / 256), dim3(256), 0, s, stats_scratch, N, groups, chunks);
   const int64_t total4 = (int64_t)N * HW * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, stats_scratch, w, b, (bf16_t*)y, total4, HW,
                      C, groups, eps, swish);

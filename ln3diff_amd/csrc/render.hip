@@ -28,7 +28,7 @@
 #define NS 64            // samples per pass (coarse == fine == 64, Objaverse preset)
 #define WAVE_LDS_BYTES 8192           // per wave: 64 points x (64 B hi + 64 B lo) feature rows; reused for cdf / merge arrays
 #define WAVE_LDS_FLOATS (WAVE_LDS_BYTES / 4)
-// scalars[]: [0..15] batch-global words, then the decoder image that every workgroup copies into its LDS:
+// scalars[]: [0..15] unused, then the decoder image that every workgroup copies into its LDS:
 //   A1  : 8 fragments (split s, hidden tile jt, k-step ks) x 64 lanes x 16 B           at DEC_A1  (8 KB)
 //   A2  : rows 0-3 only: [split s][k-step s2][hi][output o] x 16 B (other rows are zero)  at DEC_A2  (1 KB)
 //   Z   : 16 zero bytes (the A2 fragment of the lanes whose row is >= 4)                  at DEC_Z
@@ -42,7 +42,13 @@
 #define DEC_B1 (DEC_B0 + 256)
 #define DEC_BYTES (DEC_B1 + 16)
 #define DEC_FLOATS (DEC_BYTES / 4)
-static_assert(DEC_OFF + DEC_FLOATS <= LN3D_RENDER_SCRATCH_FLOATS, "decoder image must fit the caller's scratch");
+// then one 8-word record per "reference call" (group of views_per_call consecutive views): [0] min ray start, [1] max ray start,
+// [2] min depth, [3] max depth, [4] any-valid-ray flag.  The reference takes these over whatever one forward() call renders
+// (renderer.py:151-155, ray_marcher.py:57-61); its video drivers call once per camera, Triplane.forward callers once per batch.
+#define GRP_OFF (DEC_OFF + DEC_FLOATS)
+#define GRP_WORDS 8
+#define MAX_GROUPS ((LN3D_RENDER_SCRATCH_FLOATS - GRP_OFF) / GRP_WORDS)
+static_assert(MAX_GROUPS >= 1024, "room for the per-call range records");
 
 #ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
 #define LN3D_RENDER_ABL 0
@@ -70,7 +76,7 @@ struct RenderP {
   const float* jitter; const float* u_fine;
   float coord_scale, bbox_min, bbox_max; int white_back;
   float* rgb; float* depth; float* wsum;
-  float* ray_limits; uint32_t* scal_u; const float* dec;
+  float* ray_limits; uint32_t* scal_u; const float* dec; int vpc;    // scal_u -> the group records
   float* coarse_sigma; float* fine_depths;
   const float* ray_o; const float* ray_d;          // optional explicit rays [V, M, 3] (ImportanceRenderer.forward seam)
   float* fine_sigma; float* coarse_coords; float* fine_coords;
@@ -123,9 +129,12 @@ __device__ __forceinline__ void split_bf16(float f, bf16_t& h, bf16_t& l) {
 // One launch per render call: resets the batch-global words and builds the decoder's LDS image (see DEC_* above).
 //   FullyConnectedLayer weight_gain 1/sqrt(fan_in) (nsr/networks_stylegan2.py:122-157) is applied here; layer 1 (and its bias)
 //   are pre-multiplied by log2(e) and layer 2 by ln(2): softplus(x) = ln2 * log2(1 + 2^(x log2 e)).
-__global__ void render_init_kernel(uint32_t* scal_u, float* dec, const float* w0, const float* b0, const float* w1, const float* b1) {
+__global__ void render_init_kernel(uint32_t* scal_u, int groups, float* dec, const float* w0, const float* b0, const float* w1, const float* b1) {
   const int t = threadIdx.x + blockIdx.x * blockDim.x, nt = blockDim.x * gridDim.x;
-  if (t == 0) { scal_u[0] = 0xffffffffu; scal_u[1] = 0u; scal_u[2] = 0xffffffffu; scal_u[3] = 0u; scal_u[4] = 0u; }
+  for (int g = t; g < groups; g += nt) {
+    uint32_t* r = scal_u + g * GRP_WORDS;
+    r[0] = 0xffffffffu; r[1] = 0u; r[2] = 0xffffffffu; r[3] = 0u; r[4] = 0u;
+  }
   const float g0 = 1.0f / sqrtf(32.0f) * 1.4426950408889634f, g1 = 1.0f / sqrtf(64.0f) * 0.6931471805599453f;
   char* img = reinterpret_cast<char*>(dec);
   // A1 fragment (s, jt, ks), lane (row = l31, hi): W0[jt*32 + l31][ks*16 + 8*hi + e], e = 0..7
@@ -157,9 +166,10 @@ __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_ha
   const int M = p.res * p.res;
   const int64_t nr = (int64_t)p.V * M;
   const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float tmn = 3.0e38f, tmx = -3.0e38f; int any = 0;
+  float tmn = 3.0e38f, tmx = -3.0e38f; int any = 0, grp = -1;
   if (ray < nr) {
     const int v = (int)(ray / M), pix = (int)(ray % M);
+    grp = v / p.vpc;
     float o[3], d[3], a, b;
     if (p.ray_o) {
 #pragma unroll
@@ -171,12 +181,17 @@ __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_ha
     p.ray_limits[2 * ray] = a; p.ray_limits[2 * ray + 1] = b;
     if (b > a) { tmn = a; tmx = a; any = 1; }
   }
-  tmn = wave_min(tmn); tmx = wave_max(tmx);
-  any = __any(any);
-  if ((threadIdx.x & 63) == 0 && any) {
-    atomicMin(&p.scal_u[0], enc_f(tmn));
-    atomicMax(&p.scal_u[1], enc_f(tmx));
-    atomicOr(&p.scal_u[4], 1u);
+  const int g0 = __shfl(grp, 0);
+  if (__all(grp == g0 || grp < 0) && g0 >= 0) {      // the usual case: the wave's 64 rays belong to one call
+    tmn = wave_min(tmn); tmx = wave_max(tmx);
+    any = __any(any);
+    if ((threadIdx.x & 63) == 0 && any) {
+      uint32_t* r = p.scal_u + (int64_t)g0 * GRP_WORDS;
+      atomicMin(&r[0], enc_f(tmn)); atomicMax(&r[1], enc_f(tmx)); atomicOr(&r[4], 1u);
+    }
+  } else if (any) {                                   // a wave straddling two calls (res^2 not a multiple of 64)
+    uint32_t* r = p.scal_u + (int64_t)grp * GRP_WORDS;
+    atomicMin(&r[0], enc_f(tmn)); atomicMax(&r[1], enc_f(tmx)); atomicOr(&r[4], 1u);
   }
 }
 
@@ -352,6 +367,16 @@ __device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const floa
 }
 #define RENDER_LDS_BYTES (4 * WAVE_LDS_BYTES + DEC_BYTES)
 
+__device__ __forceinline__ void flush_depth_range(uint32_t* scal_u, int grp, float dmin_l, float dmax_l, int lane) {
+  if (grp < 0) return;
+  dmin_l = wave_min(dmin_l); dmax_l = wave_max(dmax_l);
+  if (lane == 0 && dmin_l <= dmax_l) {
+    uint32_t* r = scal_u + (int64_t)grp * GRP_WORDS;
+    atomicMin(&r[2], enc_f(dmin_l));
+    atomicMax(&r[3], enc_f(dmax_l));
+  }
+}
+
 __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -361,9 +386,8 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
   const int M = p.res * p.res;
   const int64_t nrays = (int64_t)p.V * M;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const bool any_valid = p.scal_u[4] != 0u;
-  const float gmin = dec_f(p.scal_u[0]), gmax = dec_f(p.scal_u[1]);
   float dmin_l = 3.0e38f, dmax_l = -3.0e38f;
+  int cur_grp = -1;
 
   for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < nrays; ray += nwaves) {
     const int v = (int)(ray / M), pix = (int)(ray % M);
@@ -374,8 +398,14 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
     } else {
       make_ray(p.cams + 25 * v, p.res, pix, o, d);
     }
+    const int grp = v / p.vpc;
+    if (grp != cur_grp) {                                       // entering another call's rays: flush this wave's depth range
+      flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
+      dmin_l = 3.0e38f; dmax_l = -3.0e38f; cur_grp = grp;
+    }
+    const uint32_t* gr = p.scal_u + (int64_t)grp * GRP_WORDS;
     float t0 = p.ray_limits[2 * ray], t1 = p.ray_limits[2 * ray + 1];
-    if (any_valid && !(t1 > t0)) { t0 = gmin; t1 = gmax; }    // renderer.py:151-155 (sic)
+    if (gr[4] != 0u && !(t1 > t0)) { t0 = dec_f(gr[0]); t1 = dec_f(gr[1]); }    // renderer.py:151-155 (sic)
     const float* planes = p.planes + (int64_t)p.plane_index[v] * 3 * p.H * p.W * 32;
 
     // ---- coarse depths: linspace + jitter * delta
@@ -507,18 +537,15 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
       p.wsum[ray] = acc_w;
     }
   }
-  dmin_l = wave_min(dmin_l); dmax_l = wave_max(dmax_l);
-  if (lane == 0 && dmin_l <= dmax_l) {
-    atomicMin(&p.scal_u[2], enc_f(dmin_l));
-    atomicMax(&p.scal_u[3], enc_f(dmax_l));
-  }
+  flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
 }
 
-// depth = clamp(nan_to_num(depth, inf), min(all depths), max(all depths))   (ray_marcher.py:57-61)
-__global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int64_t n) {
+// depth = clamp(nan_to_num(depth, inf), min(all depths), max(all depths))   (ray_marcher.py:57-61), "all" = the call's group
+__global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int64_t n, int64_t rays_per_group) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float lo = dec_f(scal_u[2]), hi = dec_f(scal_u[3]);
+  const uint32_t* r = scal_u + (i / rays_per_group) * GRP_WORDS;
+  const float lo = dec_f(r[2]), hi = dec_f(r[3]);
   float dv = depth[i];
   if (dv != dv) dv = INFINITY;
   depth[i] = fminf(fmaxf(dv, lo), hi);
@@ -537,7 +564,10 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   p.jitter = a->jitter; p.u_fine = a->u_fine;
   p.coord_scale = (float)(2.0 / (double)a->box_warp); p.bbox_min = a->bbox_min; p.bbox_max = a->bbox_max; p.white_back = a->white_back;
   p.rgb = a->rgb; p.depth = a->depth; p.wsum = a->wsum; p.ray_limits = a->ray_limits;
-  p.scal_u = reinterpret_cast<uint32_t*>(a->scalars); p.dec = a->scalars + DEC_OFF;
+  p.scal_u = reinterpret_cast<uint32_t*>(a->scalars) + GRP_OFF; p.dec = a->scalars + DEC_OFF;
+  p.vpc = (a->views_per_call <= 0 || a->views_per_call > a->V) ? a->V : a->views_per_call;
+  const int groups = (a->V + p.vpc - 1) / p.vpc;
+  if (groups > MAX_GROUPS) return LN3D_ERR_BAD_ARG;             // render in chunks of <= MAX_GROUPS calls
   p.coarse_sigma = a->coarse_sigma; p.fine_depths = a->fine_depths;
   p.ray_o = a->ray_o; p.ray_d = a->ray_d; p.fine_sigma = a->fine_sigma; p.coarse_coords = a->coarse_coords; p.fine_coords = a->fine_coords;
   const int64_t nrays = (int64_t)a->V * a->res * a->res;
@@ -546,13 +576,13 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
+  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, groups, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
   hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
   int64_t blocks = (nrays + 3) / 4;
   const int64_t cap = 256 * 8;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, s, p);
-  hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays);
+  hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays, (int64_t)p.vpc * a->res * a->res);
   return ln3d_check_launch();
 }
 
@@ -583,13 +613,13 @@ extern "C" int ln3d_query_points(const float* planes, int H, int W, const float*
   RenderP p{};
   p.planes = planes; p.H = H; p.W = W; p.coord_scale = (float)(2.0 / (double)box_warp);
   p.bbox_min = -3.0e38f; p.bbox_max = 3.0e38f;
-  p.scal_u = reinterpret_cast<uint32_t*>(scalars); p.dec = scalars + DEC_OFF;
+  p.scal_u = reinterpret_cast<uint32_t*>(scalars) + GRP_OFF; p.dec = scalars + DEC_OFF; p.vpc = 1;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&query_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, scalars + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
+  hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, 0, scalars + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
   int64_t blocks = ((P + 63) / 64 + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, s, p, points, P, sigma, rgb);

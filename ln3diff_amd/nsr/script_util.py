@@ -37,9 +37,9 @@ class AE(nn.Module):
         latent = self.decoder.vit_decode_backbone(ret_dict, img_size)
         return self.decoder.vit_decode_postprocess(latent, ret_dict)
 
-    def decode_after_vae(self, ret_dict, c, img_size=None, return_raw_only=False):
+    def decode_after_vae(self, ret_dict, c, img_size=None, return_raw_only=False, **kwargs):
         ret_dict = self.decode_after_vae_no_render(ret_dict, img_size)
-        return self.decoder.triplane_decode(ret_dict, c)
+        return self.decoder.triplane_decode(ret_dict, c, return_raw_only=return_raw_only, **kwargs)
 
     @torch.no_grad()
     def forward(self, img=None, c=None, latent=None, behaviour='enc_dec', coordinates=None, directions=None, return_raw_only=False,
@@ -49,7 +49,7 @@ class AE(nn.Module):
         if behaviour == 'decode_after_vae_no_render':
             return self.decode_after_vae_no_render(latent, self.img_size)
         if behaviour == 'decode_after_vae':
-            return self.decode_after_vae(latent, c, self.img_size)
+            return self.decode_after_vae(latent, c, self.img_size, return_raw_only, **kwargs)
         if behaviour == 'triplane_dec':
             assert latent is not None
             return self.decoder.triplane_decode(latent, c, return_raw_only=return_raw_only, **kwargs)

@@ -81,9 +81,12 @@ class Triplane(nn.Module):
 
     @torch.no_grad()
     def forward(self, planes=None, c=None, neural_rendering_resolution=None, jitter=None, u_fine=None,
-                planes_channel_last=None, plane_index=None, return_debug=False, **_):
+                planes_channel_last=None, plane_index=None, return_debug=False, views_per_call=0, **_):
         """planes [V,96,H,W] (one tri-plane per camera row, as the reference) or
-        planes_channel_last [NP,3,H,W,32] + plane_index [V] (many views of few tri-planes)."""
+        planes_channel_last [NP,3,H,W,32] + plane_index [V] (many views of few tri-planes).
+        views_per_call: the reference reduces the ray-limit fix-up and the depth clamp range over everything ONE forward() call
+        renders; 0 = this call is one such call (reference semantics of Triplane.forward), k = every k consecutive views are
+        (the drivers, which call the reference once per camera, pass 1)."""
         res = neural_rendering_resolution or self.neural_rendering_resolution
         self.neural_rendering_resolution = res
         if not c.is_cuda:
@@ -116,7 +119,7 @@ class Triplane(nn.Module):
                             c.to(torch.float32).contiguous(), res, self._decoder_dev(dev), jitter, u_fine, rgb, depth,
                             wsum, lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
                             bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=cs,
-                            fine_depths=fd, fine_sigma=fs, coarse_coords=cc, fine_coords=fc)
+                            fine_depths=fd, fine_sigma=fs, coarse_coords=cc, fine_coords=fc, views_per_call=views_per_call)
         ret = {'feature_image': rgb, 'image_raw': rgb, 'image_depth': depth, 'weights_samples': wsum,
                'image_mask': wsum * (1 + 2 * 0.001) - 0.001,
                'shape_synthesized': {'image_depth': depth, 'depth': depth.reshape(V, M, 1)}}

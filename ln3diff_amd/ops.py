@@ -121,8 +121,10 @@ def planes_to_nchw(src, dst, NP, Cc, H, W):
 
 def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine, rgb, depth, wsum, ray_limits, scalars,
                     box_warp=0.9, bbox_min=-0.45, bbox_max=0.45, white_back=True, coarse_sigma=None, fine_depths=None,
-                    ray_o=None, ray_d=None, fine_sigma=None, coarse_coords=None, fine_coords=None, n_views=None):
-    """cams [V,25] (rays generated in-kernel) or explicit ray_o / ray_d [V, res*res, 3] (then cams may be None)."""
+                    ray_o=None, ray_d=None, fine_sigma=None, coarse_coords=None, fine_coords=None, n_views=None, views_per_call=0):
+    """cams [V,25] (rays generated in-kernel) or explicit ray_o / ray_d [V, res*res, 3] (then cams may be None).
+    views_per_call: how many consecutive views form one reference forward() call for the call-wide reductions (ray-limit fix-up,
+    depth clamp range); 0 = all of them (include/ln3d.h)."""
     a = L.RenderArgs()
     a.planes, a.H, a.W, a.plane_index, a.cams = _p(planes_cl), H, W, _p(plane_index), _p(cams)
     a.V, a.res = (cams.shape[0] if cams is not None else n_views), res
@@ -132,6 +134,7 @@ def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine
     a.rgb, a.depth, a.wsum, a.ray_limits, a.scalars = _p(rgb), _p(depth), _p(wsum), _p(ray_limits), _p(scalars)
     a.coarse_sigma, a.fine_depths = _p(coarse_sigma), _p(fine_depths)
     a.ray_o, a.ray_d, a.fine_sigma, a.coarse_coords, a.fine_coords = _p(ray_o), _p(ray_d), _p(fine_sigma), _p(coarse_coords), _p(fine_coords)
+    a.views_per_call = int(views_per_call)
     L.check(L.lib().ln3d_render_triplane(C.byref(a), _stream()), "render_triplane")
 
 

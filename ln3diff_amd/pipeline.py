@@ -9,8 +9,9 @@ What is kept: seeding (th.manual_seed(41) / seed 42 before the z draw), z shape,
 num_samples, the unconditional branch = ZERO embeddings (`force_uc_zero_embeddings`), the CFG concat order (sgm: [uc, c];
 flow matching: [c, uc]), `planes *= triplane_scaling_divider`, the AE behaviour strings, 40 cameras for the T23D video and
 `camera[:24]` for the I23D one, marching at threshold 10 on a 192^3 grid scaled to +-0.45 and rotated -90 deg about x.
-What is dropped: video encoding / logging, `th.cuda.empty_cache()` calls, and the one-camera-per-call loop (all views of a
-sample are one renderer launch; per-view results do not depend on the batching).
+What is dropped: video encoding / logging, `th.cuda.empty_cache()` calls, and the one-camera-per-call loop: all views of all
+samples are one renderer launch with `views_per_call=1`, which keeps the call-wide reductions of the reference's renderer (depth
+clamp range, ray-limit fix-up) per camera exactly as the loop has them.
 """
 import torch
 
@@ -41,7 +42,8 @@ def render_video_given_triplane(planes, rec_model, cams, triplane_scaling_divide
     pcl = ddpm_latent.get('planes_channel_last')
     if pcl is not None:
         kw['plane_index'] = torch.arange(B, device=planes.device, dtype=torch.int32).repeat_interleave(V)
-    pred = rec_model(img=None, c=cams.repeat(B, 1), latent=ddpm_latent, behaviour='triplane_dec', jitter=jitter, u_fine=u_fine, **kw)
+    # one camera per reference call (:262-283): call-wide reductions of the renderer are per view
+    pred = rec_model(img=None, c=cams.repeat(B, 1), latent=ddpm_latent, behaviour='triplane_dec', jitter=jitter, u_fine=u_fine, views_per_call=1, **kw)
     for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
         out[k] = pred[k].view(B, V, *pred[k].shape[1:])
     if 'latent_after_vit' in ddpm_latent:
@@ -122,7 +124,7 @@ class T23DPipeline:
         c = cams.repeat(B, 1)
         idx = torch.arange(B, device=pcl.device, dtype=torch.int32).repeat_interleave(V)
         out = self.rec_model.decoder.triplane_decoder(c=c, planes_channel_last=pcl, plane_index=idx,
-                                                      neural_rendering_resolution=res, jitter=jitter, u_fine=u_fine)
+                                                      neural_rendering_resolution=res, jitter=jitter, u_fine=u_fine, views_per_call=1)
         return {k: (v.view(B, V, *v.shape[1:]) if torch.is_tensor(v) else v) for k, v in out.items()
                 if k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask')}
 

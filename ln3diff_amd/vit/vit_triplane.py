@@ -167,7 +167,7 @@ class RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout
     def _gn(self, x, nw, N, HW, C, swish=True):
         ws = self._ws
         y = ws.get('gn', (N * HW, C), torch.bfloat16)
-        st = ws.get('gn_stats', (N * 64,), torch.float32)
+        st = ws.get('gn_stats', (N * 64 * (1 + (HW + 255) // 256),), torch.float32)        # sums + per-chunk partials (ln3d.h)
         ops.groupnorm_swish(x, nw[0], nw[1], y, st, N, HW, C, 32, 1e-6, swish)
         return y
 

@@ -77,6 +77,32 @@ def trilatent_pos_embed(D, plane_n=3, tokens_per_plane=256):
 
 
 # ----------------------------------------------------------------- primitives
+# Operand-rounding emulation (test infrastructure for the precision argument of DESIGN.md): with OPERAND_ROUND[0] = torch.bfloat16
+# every GEMM operand (activations, weights, attention q/k/v and probabilities) is rounded to bf16 and the product accumulated
+# in fp32 - the arithmetic of the HIP path's MFMA kernels.  The HIP forward must agree with THIS restatement an order of
+# magnitude more tightly than with the fp32 one; what is left is accumulation order and rounding-boundary flips.
+OPERAND_ROUND = [None]
+
+
+class operand_rounding:
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev, OPERAND_ROUND[0] = OPERAND_ROUND[0], self.dtype
+
+    def __exit__(self, *a):
+        OPERAND_ROUND[0] = self.prev
+
+
+def _r(x):
+    return x if OPERAND_ROUND[0] is None or x is None else x.to(OPERAND_ROUND[0]).to(x.dtype)
+
+
+def linear(x, w, b=None):
+    return F.linear(_r(x), _r(w), b)
+
+
 def layer_norm(x, eps=1e-6, w=None, b=None):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -89,51 +115,56 @@ def rms_norm(x, w, eps=1e-5):
 
 def sdpa(q, k, v):
     """q,k,v [B,H,N,Dh]: softmax(q k^T / sqrt(Dh)) v, no mask, no dropout."""
-    s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
-    return torch.softmax(s, dim=-1) @ v
+    if OPERAND_ROUND[0] is None:
+        s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+        return torch.softmax(s, dim=-1) @ v
+    # the kernels' arithmetic: q pre-scaled then rounded, un-normalised probabilities rounded for the P.V product, fp32 row sum
+    s = _r(q * (q.shape[-1] ** -0.5)) @ _r(k).transpose(-1, -2)
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    return (_r(p) @ _r(v)) / p.sum(-1, keepdim=True)
 
 
 def self_attention(sd, p, x, H):
     B, N, C = x.shape
-    qkv = F.linear(x, sd[p + 'qkv.weight'], sd[p + 'qkv.bias']).reshape(B, N, 3, H, C // H)
+    qkv = linear(x, sd[p + 'qkv.weight'], sd[p + 'qkv.bias']).reshape(B, N, 3, H, C // H)
     q, k, v = qkv.unbind(2)                                  # [B,N,H,Dh]
     if p + 'q_norm.weight' in sd:
         q = rms_norm(q, sd[p + 'q_norm.weight'])
         k = rms_norm(k, sd[p + 'k_norm.weight'])
     o = sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
     o = o.transpose(1, 2).reshape(B, N, C)
-    return F.linear(o, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
+    return linear(o, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
 
 
 def cross_attention(sd, p, x, ctx, H, dim_head=64):
     B = x.shape[0]
-    q = F.linear(x, sd[p + 'to_q.weight'])
-    k = F.linear(ctx, sd[p + 'to_k.weight'])
-    v = F.linear(ctx, sd[p + 'to_v.weight'])
+    q = linear(x, sd[p + 'to_q.weight'])
+    k = linear(ctx, sd[p + 'to_k.weight'])
+    v = linear(ctx, sd[p + 'to_v.weight'])
     sp = lambda t: t.reshape(B, t.shape[1], H, dim_head).transpose(1, 2)
     q, k, v = sp(q), sp(k), sp(v)
     if p + 'q_norm.weight' in sd:
         q = rms_norm(q, sd[p + 'q_norm.weight'])
         k = rms_norm(k, sd[p + 'k_norm.weight'])
     o = sdpa(q, k, v).transpose(1, 2).reshape(B, x.shape[1], H * dim_head)
-    return F.linear(o, sd[p + 'to_out.0.weight'], sd[p + 'to_out.0.bias'])
+    return linear(o, sd[p + 'to_out.0.weight'], sd[p + 'to_out.0.bias'])
 
 
 def fused_mlp(sd, p, x):
-    h = F.linear(x, sd[p + 'mlp.0.weight']) + sd[p + 'mlp.1.bias']
+    h = linear(x, sd[p + 'mlp.0.weight']) + sd[p + 'mlp.1.bias']
     h = F.gelu(h)                                            # erf GELU
-    return F.linear(h, sd[p + 'mlp.2.weight']) + sd[p + 'mlp.3.bias']
+    return linear(h, sd[p + 'mlp.2.weight']) + sd[p + 'mlp.3.bias']
 
 
 def caption_embedder(sd, p, c):
-    h = F.linear(c, sd[p + 'y_proj.fc1.weight'], sd[p + 'y_proj.fc1.bias'])
+    h = linear(c, sd[p + 'y_proj.fc1.weight'], sd[p + 'y_proj.fc1.bias'])
     h = F.gelu(h, approximate='tanh')
-    return F.linear(h, sd[p + 'y_proj.fc2.weight'], sd[p + 'y_proj.fc2.bias'])
+    return linear(h, sd[p + 'y_proj.fc2.weight'], sd[p + 'y_proj.fc2.bias'])
 
 
 def t_embedder(sd, t):
-    h = F.linear(timestep_embedding(t), sd['t_embedder.mlp.0.weight'], sd['t_embedder.mlp.0.bias'])
-    return F.linear(F.silu(h), sd['t_embedder.mlp.2.weight'], sd['t_embedder.mlp.2.bias'])
+    h = linear(timestep_embedding(t), sd['t_embedder.mlp.0.weight'], sd['t_embedder.mlp.0.bias'])
+    return linear(F.silu(h), sd['t_embedder.mlp.2.weight'], sd['t_embedder.mlp.2.bias'])
 
 
 def patchify_embed(sd, x, patch=2):
@@ -159,7 +190,7 @@ def unpatchify_trilatent(y, B, patch, c_out):
 
 # --------------------------------------------------------------------- T23D
 def t23d_block(sd, p, x, t_emb, ctx, H):
-    mod = F.linear(F.silu(t_emb), sd[p + 'adaLN_modulation.1.weight'], sd[p + 'adaLN_modulation.1.bias'])
+    mod = linear(F.silu(t_emb), sd[p + 'adaLN_modulation.1.weight'], sd[p + 'adaLN_modulation.1.bias'])
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
     h = layer_norm(x) * (1 + sc_a[:, None]) + sh_a[:, None]
     x = x + g_a[:, None] * self_attention(sd, p + 'attn.', h, H)
@@ -181,11 +212,11 @@ def t23d_forward(sd, x, timesteps, context, num_heads, patch=2, return_tokens=Fa
         h = t23d_block(sd, f'blocks.{i}.', h, t_emb, ctx, num_heads)
     if return_tokens:
         return h
-    mod = F.linear(F.silu(t_emb), sd['final_layer.adaLN_modulation.1.weight'],
+    mod = linear(F.silu(t_emb), sd['final_layer.adaLN_modulation.1.weight'],
                    sd['final_layer.adaLN_modulation.1.bias'])
     shift, scale = mod.chunk(2, dim=1)
     y = layer_norm(h) * (1 + scale[:, None]) + shift[:, None]
-    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])     # fp32 in the HIP path too (final_layer kernel)
     c_out = y.shape[-1] // (patch * patch)
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
@@ -208,19 +239,19 @@ def i23d_forward(sd, x, timesteps, context, num_heads, patch=2, clip_ctx_dim=102
     B = x.shape[0]
     depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
     vec = context['vector'].float()
-    cls = F.linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
+    cls = linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
                    sd['cap_embedder.1.weight'], sd['cap_embedder.1.bias'])
     ca = context['crossattn'].float()
     clip_tok = rms_norm(ca[..., :clip_ctx_dim], sd['attention_y_norm.weight'])
     dino_tok = caption_embedder(sd, 'dino_proj.', ca[..., clip_ctx_dim:])
     t = t_embedder(sd, timesteps.float()) + cls
-    t0 = F.linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    t0 = linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
     h = patchify_embed(sd, x, patch) + sd['pos_embed']
     for i in range(depth):
         h = i23d_block(sd, f'blocks.{i}.', h, t0, dino_tok, clip_tok, num_heads)
     shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
     y = layer_norm(h) * (1 + scale) + shift
-    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])     # fp32 in the HIP path too (final_layer kernel)
     c_out = y.shape[-1] // (patch * patch)
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
@@ -232,19 +263,19 @@ def i23d_mv_forward(sd, x, timesteps, context, num_heads, patch=2):
     B = x.shape[0]
     depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
     vec = context['vector'].float()
-    cls = F.linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
+    cls = linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
                    sd['cap_embedder.1.weight'], sd['cap_embedder.1.bias'])
     clip_tok = caption_embedder(sd, 'clip_spatial_proj.', context['crossattn'].float())
     mv = context['concat'].float()
     dino_tok = mv.reshape(B, mv.shape[1] * mv.shape[2], mv.shape[3])
     t = t_embedder(sd, timesteps.float()) + cls
-    t0 = F.linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    t0 = linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
     h = patchify_embed(sd, x, patch) + sd['pos_embed']
     for i in range(depth):
         h = i23d_block(sd, f'blocks.{i}.', h, t0, clip_tok, dino_tok, num_heads)       # (appended, cross-attended)
     shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
     y = layer_norm(h) * (1 + scale) + shift
-    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])     # fp32 in the HIP path too (final_layer kernel)
     c_out = y.shape[-1] // (patch * patch)
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
@@ -259,14 +290,14 @@ def i23d_mv_noclip_forward(sd, x, timesteps, context, num_heads, patch=2):
     mv = context['concat'].float()
     dino_tok = mv.reshape(B, mv.shape[1] * mv.shape[2], mv.shape[3])
     t = t_embedder(sd, timesteps.float())
-    t0 = F.linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    t0 = linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
     h = patchify_embed(sd, x, patch) + sd['pos_embed']
     none = h.new_zeros(B, 0, h.shape[-1])
     for i in range(depth):
         h = i23d_block(sd, f'blocks.{i}.', h, t0, none, dino_tok, num_heads)
     shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
     y = layer_norm(h) * (1 + scale) + shift
-    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])     # fp32 in the HIP path too (final_layer kernel)
     c_out = y.shape[-1] // (patch * patch)
     return unpatchify_trilatent(y, B, patch, c_out).float()
 

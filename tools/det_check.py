@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Bitwise run-to-run determinism of the GEMM epilogues / norm kernels at the DiT-L/2 shapes (GPU box)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from ln3diff_amd import ops
 dev = 'cuda'
 M = 16 * 768
@@ -31,3 +32,14 @@ Lc, lpad = 77, 128
 kcx = torch.zeros(16, 16, lpad, 64, device=dev, dtype=torch.bfloat16); kcx[:, :, :Lc] = torch.randn(16, 16, Lc, 64, device=dev).to(torch.bfloat16)
 vtx = torch.randn(16, 16, 64, lpad, device=dev).to(torch.bfloat16); wq1 = (torch.randn(1024, 1024, device=dev) * 0.03).to(torch.bfloat16); oc = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
 chk('to_q + cross-attn', lambda: ops.gemm(x, wq1, None, ops.EPI_CROSS_ATTN, oc, kcx, vtx, M=M, tokens=768, heads=16, head_dim=64, ctx_keys=Lc, ctx_pad=lpad, ctx_scale=0.125), lambda: [oc])
+# VAE decode (GroupNorm statistics are reduced in a fixed order since r2; fp32 atomics there made the planes differ by 3e-2)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from test_decode_gpu import build_decoder
+from conftest import load_synth
+from ln3diff_amd.synth import synth_input
+dec = build_decoder(128, 2, 2); load_synth(dec, 0); dec = dec.cuda()
+lat = {'latent_normalized_2Ddiffusion': synth_input('latent', (2, 12, 32, 32), 5).cuda()}
+outs = []
+def fdec():
+    outs[:] = [dec.vit_decode_postprocess(dec.vit_decode_backbone(lat, 128), {})['latent_after_vit']]
+chk('VAE decode (tiny)', fdec, lambda: outs)
