@@ -126,6 +126,10 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P, ws = self._packed, self._ws
         Bn, Lc, _ = ca.shape
         D, H, C1 = self.embed_dim, self.num_heads, self.clip_ctx_dim
+        want = C1 + self.dino_proj.y_proj.fc1.in_features
+        if ca.shape[-1] != want or vec.shape[-1] != self.pooling_ctx_dim:
+            raise ValueError(f"context['crossattn'] must be [B, L, {want}] (CLIP {C1} || DINO) and context['vector'] [B, {self.pooling_ctx_dim}]; "
+                             f"got {tuple(ca.shape)} / {tuple(vec.shape)}")
         cls = self._cls_token(vec)
         # CLIP tokens: RMSNorm once (dit_i23d.py:247); DINO tokens: tanh-GELU MLP
         clip_n = ws.get('clip_n', (Bn * Lc, C1), torch.bfloat16)
@@ -241,6 +245,9 @@ class DiT_I23D_PixelArt_MVCond(DiT_I23D_PixelArt):
     @torch.no_grad()
     def prepare_context(self, context):
         ca, vec, mv = context['crossattn'], context['vector'], context['concat']
+        if ca.shape[-1] != self.clip_spatial_proj.y_proj.fc1.in_features or mv.dim() != 4:
+            raise ValueError(f"MVCond context: 'crossattn' [B, L, {self.clip_spatial_proj.y_proj.fc1.in_features}] (CLIP spatial tokens), "
+                             f"'concat' [B, V, L, C] (multi-view DINO); got {tuple(ca.shape)} / {tuple(mv.shape)}")
         self._ensure_packed(ca.device)
         ws = self._ws
         Bn = ca.shape[0]

@@ -31,6 +31,8 @@ def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, 
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     a = L.GemmArgs()
     K = w.shape[1]
+    if x.shape[-1] != K:
+        raise ValueError(f"gemm: activation has {x.shape[-1]} input features, the weight expects {K}")
     a.X, a.ldx, a.W, a.ldw = _p(x), x.stride(-2) if x.dim() > 1 else K, _p(w), w.stride(0)
     a.bias = _p(bias)
     a.M = int(M if M is not None else x.numel() // K)

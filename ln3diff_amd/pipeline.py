@@ -190,3 +190,55 @@ class FlowMatchingEngine:
 
 
 I23DPipeline = FlowMatchingEngine
+
+
+class GuidedDiffusionEngine:
+    """The guided_diffusion engines of the ShapeNet / FFHQ entry point (scripts/vit_triplane_diffusion_sample.py):
+    TrainLoop3DDiffusion.eval_ddpm_sample (nsr/train_util_diffusion.py:863-921) and TrainLoop3DDiffusionLSGM_crossattn.eval_cldm
+    (nsr/lsgm/crossattn_cldm.py:510-640): `SpacedDiffusion.p_sample_loop` - or `ddim_sample_loop` with classifier-free guidance
+    when use_ddim - over the denoiser, then render_video_given_triplane per sample.  The reference passes mixing_normal=True,
+    which reads `ddpm_model.mixing_logit`; its DiT classes do not define one (dit/dit_models_xformers.py:767-772 is commented
+    out), so that branch only ever ran with the U-Net denoiser, which is outside the hot path: mixing is off here."""
+
+    def __init__(self, ddpm_model, decoder, diffusion, conditioner=None, triplane_scaling_divider=1.0, img_size=128, batch_size=1,
+                 diffusion_input_size=32):
+        from .nsr.script_util import AE
+        self.ddpm_model, self.diffusion, self.conditioner = ddpm_model, diffusion, conditioner
+        self.rec_model = decoder if isinstance(decoder, AE) else AE(None, decoder, img_size)
+        self.triplane_scaling_divider = triplane_scaling_divider
+        self.batch_size, self.diffusion_input_size = batch_size, diffusion_input_size
+
+    def _noise_size(self, batch_size, overwrite_diff_inp_size=None):
+        m = self.ddpm_model
+        S = int(overwrite_diff_inp_size) if overwrite_diff_inp_size else self.diffusion_input_size
+        return (batch_size, 3 * m.in_channels if m.roll_out else m.in_channels, S, S)
+
+    @torch.no_grad()
+    def sample(self, cond=None, batch_size=None, use_ddim=False, unconditional_guidance_scale=1.0, clip_denoised=False, noise=None,
+               overwrite_diff_inp_size=None, device=None):
+        B = batch_size or self.batch_size
+        shape = self._noise_size(B, overwrite_diff_inp_size)
+        device = device or next(self.ddpm_model.parameters()).device
+        if cond is not None:
+            c = cond['crossattn'] if isinstance(cond, dict) and 'crossattn' in cond else cond
+            c = c if not torch.is_tensor(c) or c.shape[0] == B else c.repeat_interleave(B, 0)        # broadcast to batch_size (:573-577)
+        else:
+            c = None
+        if noise is None:
+            noise = torch.randn(*shape, device=device)
+        if use_ddim:
+            return self.diffusion.ddim_sample_loop(self.ddpm_model, shape, cond=c, noise=noise, clip_denoised=clip_denoised,
+                                                   unconditional_guidance_scale=unconditional_guidance_scale, device=device)
+        return self.diffusion.p_sample_loop(self.ddpm_model, shape, cond=c, noise=noise, clip_denoised=clip_denoised, device=device)
+
+    @torch.no_grad()
+    def eval_cldm(self, cond, camera, use_ddim=False, unconditional_guidance_scale=1.0, export_mesh=False, resolution=None,
+                  overwrite_diff_inp_size=None, **render_kw):
+        latent = self.sample(cond, use_ddim=use_ddim, unconditional_guidance_scale=unconditional_guidance_scale,
+                             overwrite_diff_inp_size=overwrite_diff_inp_size)
+        return latent, render_video_given_triplane(latent.clone(), self.rec_model, camera, self.triplane_scaling_divider,
+                                                   export_mesh=export_mesh, resolution=resolution, **render_kw)
+
+    @torch.no_grad()
+    def eval_ddpm_sample(self, camera, **kw):
+        return self.eval_cldm(None, camera, **kw)

@@ -74,7 +74,7 @@ class FrozenCLIPEmbedder(nn.Module):
     LAYERS = ["last", "pooled", "hidden"]
 
     def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77, freeze=True, layer="last",
-                 layer_idx=None, always_return_pooled=False, **model_kwargs):
+                 layer_idx=None, always_return_pooled=False, tokenizer_dir=None, **model_kwargs):
         super().__init__()
         assert layer in self.LAYERS
         if layer == "hidden":
@@ -83,6 +83,7 @@ class FrozenCLIPEmbedder(nn.Module):
         self.layer, self.return_pooled = layer, always_return_pooled
         self.transformer = CLIPTextModel(**model_kwargs)
         self._tok = None
+        self.tokenizer_dir = tokenizer_dir          # directory with vocab.json + merges.txt -> ln3diff_amd.sgm.tokenizer (no hub cache needed)
         self._packed = None
         _cache.watch(self)
         if freeze:
@@ -95,6 +96,10 @@ class FrozenCLIPEmbedder(nn.Module):
 
     # ------------------------------------------------------------------ tokenizer (third-party data files)
     def tokenize(self, text):
+        if self._tok is None and self.tokenizer_dir:
+            from .tokenizer import CLIPTokenizer as OwnTokenizer
+            own = OwnTokenizer(self.tokenizer_dir, max_length=self.max_length)
+            self._tok = lambda text, **kw: {"input_ids": own(text)}
         if self._tok is None:
             try:
                 from transformers import CLIPTokenizer

@@ -1,0 +1,56 @@
+"""Entry-point flag surface and up-front validation (no GPU): scripts/vit_triplane_diffusion_sample{,_objaverse}.py -> ln3diff_amd.entry."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from ln3diff_amd.entry import TRAINERS, create_argparser, validate
+
+
+def _args(objaverse=True, *flags):
+    return create_argparser(objaverse).parse_known_args(list(flags))[0]
+
+
+def test_reference_launcher_flags_parse():
+    # the released T23D launcher's flags (shell_scripts/final_release/inference/sample_obajverse_t23d_dit.sh), booleans as words
+    a, unknown = create_argparser(True).parse_known_args(
+        "--dit_model_arch DiT-L/2 --trainer_name sgm_legacy --num_samples 4 --unconditional_guidance_scale 6.5 "
+        "--triplane_scaling_divider 0.96806 --export_mesh True --use_amp False --lr 1e-4 --batch_size 4 --logdir /tmp/x "
+        "--some_training_only_flag 3".split())
+    assert a.dit_model_arch == 'DiT-L/2' and a.export_mesh is True and a.triplane_scaling_divider == 0.96806
+    assert unknown == ['--some_training_only_flag', '3']
+    assert validate(a) == 'edm'
+    b = _args(False)
+    assert b.trainer_name == 'adm' and b.triplane_scaling_divider == 1.0 and validate(b) == 'gd'
+
+
+@pytest.mark.parametrize("flags,msg", [
+    (("--dit_model_arch", "DiT-PixArt-L/2"), "I23D architecture"),                       # I23D arch without --i23d
+    (("--i23d", "true", "--dit_model_arch", "DiT-L/2", "--trainer_name", "flow_matching"), "T23D architecture"),
+    (("--i23d", "true", "--dit_model_arch", "DiT-PixArt-L/2"), "flow-matching"),         # I23D with the EDM engine
+    (("--trainer_name", "no_such"), "known engines"),
+    (("--create_controlnet", "true"), "ControlNet"),
+    (("--arch_dit_decoder", "DiT2-Z/9"), "arch_dit_decoder"),
+    (("--num_samples", "0"), ">= 1"),
+])
+def test_unrunnable_flag_combinations_are_refused(flags, msg):
+    with pytest.raises(SystemExit) as e:
+        validate(_args(True, *flags))
+    assert msg in str(e.value)
+
+
+def test_trainer_table_covers_the_reference_names():
+    for name in ('sgm_legacy', 'flow_matching', 'adm', 'vpsde_crossattn'):
+        assert name in TRAINERS
+
+
+@pytest.mark.parametrize("script", ["vit_triplane_diffusion_sample_objaverse.py", "vit_triplane_diffusion_sample.py"])
+def test_scripts_fail_loudly_without_gpu(script):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), "--logdir", "/tmp/ln3d_entry_test"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)

@@ -1,0 +1,38 @@
+"""The two entry points end to end on the GPU (small registry models, few steps): every engine of the trainer table samples, renders,
+exports a mesh and writes its outputs; results do not depend on how the batch is sharded."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ln3diff_amd.entry import create_argparser, run
+
+pytestmark = pytest.mark.gpu
+
+SMALL = "--arch_dit_decoder DiT2-B/2 --num_samples 2 --sample_steps 4 --image_size 32 --num_views 2 --mesh_grid 24"
+
+
+@pytest.mark.parametrize("objaverse,flags", [
+    (True, "--dit_model_arch DiT-B/2 --trainer_name sgm_legacy --export_mesh true --mesh_thres 4.0"),
+    (True, "--dit_model_arch DiT-PixArt-B/2 --i23d true --trainer_name flow_matching --unconditional_guidance_scale 4.0"),
+    (True, "--dit_model_arch DiT-PixArt-MV-B/2 --i23d true --trainer_name flow_matching --num_mv_views 2"),
+    (False, "--dit_model_arch DiT-B/2 --trainer_name adm --timestep_respacing 4"),
+    (False, "--dit_model_arch DiT-B/2 --trainer_name vpsde_crossattn --use_ddim true --timestep_respacing ddim4 --unconditional_guidance_scale 3.0"),
+])
+def test_entry_points_run(hip_lib, tmp_path, objaverse, flags):
+    args = create_argparser(objaverse).parse_args((SMALL + " " + flags + f" --logdir {tmp_path}").split())
+    lat = run(args)
+    assert lat.shape == (2, 12, 32, 32) and torch.isfinite(lat).all()
+    frames = np.load(tmp_path / "frames_rank0.npy")
+    assert frames.shape == (2, 2, 3, 32, 32) and np.isfinite(frames).all()
+    assert np.array_equal(np.load(tmp_path / "latents_all.npy"), lat.cpu().numpy())
+    assert os.path.exists(tmp_path / "sample1_view0.ppm") and os.path.exists(tmp_path / "args.json")
+    if args.export_mesh:
+        assert os.path.exists(tmp_path / "mesh_sample0.obj") and os.path.exists(tmp_path / "mesh_sample1.obj")   # content: test_mesh_gpu.py
+    # the divider is applied: a different --triplane_scaling_divider changes the frames, not the latents
+    args2 = create_argparser(objaverse).parse_args((SMALL + " " + flags + f" --logdir {tmp_path}/b --triplane_scaling_divider 0.5").split())
+    args2.export_mesh = False
+    lat2 = run(args2)
+    assert torch.equal(lat2, lat)
+    assert not np.array_equal(np.load(tmp_path / "b" / "frames_rank0.npy"), frames)
