@@ -439,7 +439,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 //    feature tiles in groups of 4, so concurrently running tiles share 4 W panels and its own X panels.
 //  * Epilogue through LDS (staged_epilogue) except V^T tiles.
 template <int EPI, int NW, int WGT, int NI, int NJ>
-__global__ __launch_bounds__(NW * 64, NW / 4) void gemm_bf16_ring64_kernel(GemmP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) void gemm_bf16_ring64_kernel(GemmP p) {
   constexpr int WGF = NW / WGT, BF = 32 * NI * WGF, BT = 32 * NJ * WGT;
   constexpr int WB = BF * 128, STAGEB = (BF + BT) * 128, NPW = (BF + BT) / 8 / NW;
   static_assert((BF + BT) / 8 % NW == 0, "DMA instructions must divide evenly over the waves");
@@ -816,6 +816,8 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
     case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
     case 11: return launch_ring64<EPI, 8, 2, 3, 3>(p, s);
     case 12: return launch_ring64<EPI, 12, 2, 2, 3>(p, s);
+    case 13: return launch_ring64<EPI, 4, 2, 4, 4>(p, s);
+    case 14: return launch_ring64<EPI, 4, 2, 2, 3>(p, s);      // 128f x 192t, 4 waves, 80 KB: two workgroups per CU (epilogue of one under the main loop of the other)      // 256x256, 4 waves (1 per SIMD), 128x128 wave tiles, accumulators in AGPRs
     default: return launch<EPI>(p, s);
   }
 }

@@ -50,6 +50,9 @@
 #define MAX_GROUPS ((LN3D_RENDER_SCRATCH_FLOATS - GRP_OFF) / GRP_WORDS)
 static_assert(MAX_GROUPS >= 1024, "room for the per-call range records");
 
+#ifndef RENDER_OCC
+#define RENDER_OCC 3
+#endif
 #ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
 #define LN3D_RENDER_ABL 0
 #endif
@@ -208,45 +211,58 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
                                         float px, float py, float pz, int lane, float rgb[3], float& sigma) {
   const int g = lane >> 3, c4 = lane & 7;
   const float sx = px * p.coord_scale, sy = py * p.coord_scale, sz = pz * p.coord_scale;
-  const int64_t plane_stride = (int64_t)p.H * p.W * 32;
-#pragma unroll 1
-  for (int it = 0; it < 8; ++it) {
+  const int plane_stride = p.H * p.W * 32;
+  // ---- bilinear setup, ONCE per point (this lane's own point): per plane 4 clamped tap offsets (bytes, channel 0 of the texel)
+  // and 4 tap weights with the zero-padding mask folded in.  The gather below has 8 lanes cooperate on one point's texels (one
+  // 128-B line per tap per point); they fetch the owner's setup with ds_bpermute instead of recomputing it 8 times - the
+  // address / weight arithmetic was 200 of the 252 VALU instructions of a gather iteration (profiles/r2_render_pmc.md).
+  int toff[12];
+  float tw[12];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const float gx = pl == 0 ? sx : (pl == 1 ? sy : sz);     // (x,y) (y,z) (z,x)
+    const float gy = pl == 0 ? sy : (pl == 1 ? sz : sx);
+    const float ix = ((gx + 1.f) * p.W - 1.f) * 0.5f, iy = ((gy + 1.f) * p.H - 1.f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float w_nw = (fx0 + 1.f - ix) * (fy0 + 1.f - iy), w_ne = (ix - fx0) * (fy0 + 1.f - iy);
+    const float w_sw = (fx0 + 1.f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
+    // branch-free taps: out-of-range texels are read at a clamped (valid) address and weighted by 0, so the 12 loads of an
+    // iteration are issued back to back (conditional loads cost one L2 round trip each: the compiler waits per branch)
+    const bool xin0 = x0 >= 0 && x0 < p.W, xin1 = x0 + 1 >= 0 && x0 + 1 < p.W;
+    const bool yin0 = y0 >= 0 && y0 < p.H, yin1 = y0 + 1 >= 0 && y0 + 1 < p.H;
+    const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x0 + 1, 0), p.W - 1);
+    const int yc0 = min(max(y0, 0), p.H - 1), yc1 = min(max(y0 + 1, 0), p.H - 1);
+    tw[4 * pl + 0] = (xin0 && yin0) ? w_nw : 0.f; tw[4 * pl + 1] = (xin1 && yin0) ? w_ne : 0.f;
+    tw[4 * pl + 2] = (xin0 && yin1) ? w_sw : 0.f; tw[4 * pl + 3] = (xin1 && yin1) ? w_se : 0.f;
+    const int pb = pl * plane_stride;
+    toff[4 * pl + 0] = (pb + (yc0 * p.W + xc0) * 32) * 4; toff[4 * pl + 1] = (pb + (yc0 * p.W + xc1) * 32) * 4;
+    toff[4 * pl + 2] = (pb + (yc1 * p.W + xc0) * 32) * 4; toff[4 * pl + 3] = (pb + (yc1 * p.W + xc1) * 32) * 4;
+  }
+  const char* pbase = reinterpret_cast<const char*>(planes) + c4 * 16;
+  auto fetch = [&](int it, float4 (&t)[12], float (&a)[12]) {
+    const int bsel = (it * 8 + g) << 2;                   // ds_bpermute byte address of the owner lane
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int off = __builtin_amdgcn_ds_bpermute(bsel, toff[k]);
+      a[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsel, __float_as_int(tw[k])));
+      if constexpr (!(LN3D_RENDER_ABL & 2)) t[k] = *reinterpret_cast<const float4*>(pbase + off);
+      else t[k] = make_float4(a[k], (float)off, 1.f, 2.f);
+    }
+  };
+  auto reduce = [&](int it, const float4 (&t)[12], const float (&a)[12]) {
     const int src = it * 8 + g;
-    const float qx = __shfl(sx, src, 64), qy = __shfl(sy, src, 64), qz = __shfl(sz, src, 64);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      const float gx = pl == 0 ? qx : (pl == 1 ? qy : qz);     // (x,y) (y,z) (z,x)
-      const float gy = pl == 0 ? qy : (pl == 1 ? qz : qx);
-      const float ix = ((gx + 1.f) * p.W - 1.f) * 0.5f, iy = ((gy + 1.f) * p.H - 1.f) * 0.5f;
-      const float fx0 = floorf(ix), fy0 = floorf(iy);
-      const int x0 = (int)fx0, y0 = (int)fy0;
-      const float w_nw = (fx0 + 1.f - ix) * (fy0 + 1.f - iy), w_ne = (ix - fx0) * (fy0 + 1.f - iy);
-      const float w_sw = (fx0 + 1.f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
-      // branch-free taps: out-of-range texels are read at a clamped (valid) address and weighted by 0, so the 12 loads of an
-      // iteration are issued back to back (conditional loads cost one L2 round trip each: the compiler waits per branch)
-      const bool xin0 = x0 >= 0 && x0 < p.W, xin1 = x0 + 1 >= 0 && x0 + 1 < p.W;
-      const bool yin0 = y0 >= 0 && y0 < p.H, yin1 = y0 + 1 >= 0 && y0 + 1 < p.H;
-      const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x0 + 1, 0), p.W - 1);
-      const int yc0 = min(max(y0, 0), p.H - 1), yc1 = min(max(y0 + 1, 0), p.H - 1);
-      const float a_nw = (xin0 && yin0) ? w_nw : 0.f, a_ne = (xin1 && yin0) ? w_ne : 0.f;
-      const float a_sw = (xin0 && yin1) ? w_sw : 0.f, a_se = (xin1 && yin1) ? w_se : 0.f;
-      const float* base = planes + pl * plane_stride + c4 * 4;
-      float4 t0, t1, t2, t3;
-      if constexpr (!(LN3D_RENDER_ABL & 2)) {
-        t0 = *reinterpret_cast<const float4*>(base + (yc0 * p.W + xc0) * 32);
-        t1 = *reinterpret_cast<const float4*>(base + (yc0 * p.W + xc1) * 32);
-        t2 = *reinterpret_cast<const float4*>(base + (yc1 * p.W + xc0) * 32);
-        t3 = *reinterpret_cast<const float4*>(base + (yc1 * p.W + xc1) * 32);
-      } else {
-        t0 = t1 = t2 = t3 = make_float4(ix, iy, gx, gy);
-      }
       // same evaluation order as the reference's grid_sample: ((nw + ne) + sw) + se per channel
       float4 s;
-      s.x = t0.x * a_nw; s.y = t0.y * a_nw; s.z = t0.z * a_nw; s.w = t0.w * a_nw;
-      s.x += t1.x * a_ne; s.y += t1.y * a_ne; s.z += t1.z * a_ne; s.w += t1.w * a_ne;
-      s.x += t2.x * a_sw; s.y += t2.y * a_sw; s.z += t2.z * a_sw; s.w += t2.w * a_sw;
-      s.x += t3.x * a_se; s.y += t3.y * a_se; s.z += t3.z * a_se; s.w += t3.w * a_se;
+      s.x = t[4 * pl].x * a[4 * pl]; s.y = t[4 * pl].y * a[4 * pl]; s.z = t[4 * pl].z * a[4 * pl]; s.w = t[4 * pl].w * a[4 * pl];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        s.x += t[4 * pl + k].x * a[4 * pl + k]; s.y += t[4 * pl + k].y * a[4 * pl + k];
+        s.z += t[4 * pl + k].z * a[4 * pl + k]; s.w += t[4 * pl + k].w * a[4 * pl + k];
+      }
       acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
     }
     // mean over the 3 planes.  torch divides (sum / 3); a multiply by the fp32 reciprocal differs by <= 1 ulp - far inside the
@@ -264,6 +280,17 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     char* row = wl + src * 128 + (c4 & 1) * 8;
     *reinterpret_cast<uint2*>(row + (((c4 >> 1) ^ key) << 4)) = hv;
     *reinterpret_cast<uint2*>(row + (((4 + (c4 >> 1)) ^ key) << 4)) = lv;
+  };
+  {
+    // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
+    // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
+    float4 tA[12];
+    float aA[12];
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+      fetch(it, tA, aA);
+      reduce(it, tA, aA);
+    }
   }
   wave_sync();
   const int l31 = lane & 31, hi = lane >> 5;
@@ -325,7 +352,8 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
       // rows 0-3 = (sigma, r, g, b) of point pt*32 + l31, in registers 0-3 of lanes 0-31
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float v = __shfl(oacc[k], l31, 64);
+        // point tile 0 lives in the lanes that hold its results already; tile 1's results move up by 32 lanes
+        const float v = pt == 0 ? oacc[k] : __shfl(oacc[k], l31, 64);
         if (hi == pt) o[k] = v;
       }
     }
@@ -343,18 +371,36 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   rgb[2] = inb ? (1.0f / (1.0f + __expf(-o[3]))) * 1.002f - 0.001f : 0.f;
 }
 
-__device__ __forceinline__ float wave_excl_prod(float v, int lane) {   // exclusive prefix product over lanes
-  float x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(x, o, 64); if (lane >= o) x *= y; }
-  const float e = __shfl_up(x, 1, 64);
-  return lane == 0 ? 1.0f : e;
+// ---- wave-wide scans / reductions / neighbour shifts on the DPP cross-lane path (gfx9 row_shr / row_bcast / wave_shr controls):
+// a VALU-rate instruction each instead of a ds_bpermute round trip through the LDS (the per-ray code has ~85 of them in
+// dependent chains).  Scan recipe = LLVM's wave64 gfx9 one: row_shr 1, 2, 4, 8 inside the rows of 16, then lane 15 of row r
+// into row r+1 (row_bcast:15, rows 1 and 3) and lane 31 into rows 2-3 (row_bcast:31).
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHL1 0x130     // lane i <- lane i+1
+#define DPP_WAVE_SHR1 0x138     // lane i <- lane i-1
+#define DPP_BCAST15 0x142
+#define DPP_BCAST31 0x143
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {     // lanes without a source keep `old`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-  float x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+__device__ __forceinline__ float lane_prev(float x, float fill) { return dpp_mov<DPP_WAVE_SHR1>(fill, x); }   // x of lane-1 (lane 0: fill)
+__device__ __forceinline__ float lane_next(float x, float fill) { return dpp_mov<DPP_WAVE_SHL1>(fill, x); }   // x of lane+1 (lane 63: fill)
+__device__ __forceinline__ float wave_incl_prod_dpp(float x) {
+  x *= dpp_mov<DPP_ROW_SHR(1)>(1.0f, x); x *= dpp_mov<DPP_ROW_SHR(2)>(1.0f, x);
+  x *= dpp_mov<DPP_ROW_SHR(4)>(1.0f, x); x *= dpp_mov<DPP_ROW_SHR(8)>(1.0f, x);
+  x *= dpp_mov<DPP_BCAST15, 0xa>(1.0f, x); x *= dpp_mov<DPP_BCAST31, 0xc>(1.0f, x);
   return x;
+}
+__device__ __forceinline__ float wave_incl_sum(float x, int) {
+  x += dpp_mov<DPP_ROW_SHR(1)>(0.0f, x); x += dpp_mov<DPP_ROW_SHR(2)>(0.0f, x);
+  x += dpp_mov<DPP_ROW_SHR(4)>(0.0f, x); x += dpp_mov<DPP_ROW_SHR(8)>(0.0f, x);
+  x += dpp_mov<DPP_BCAST15, 0xa>(0.0f, x); x += dpp_mov<DPP_BCAST31, 0xc>(0.0f, x);
+  return x;
+}
+__device__ __forceinline__ float wave_excl_prod(float v, int) { return lane_prev(wave_incl_prod_dpp(v), 1.0f); }
+__device__ __forceinline__ float wave_total(float v) {               // sum over the 64 lanes, the same value in every lane
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_sum(v, 0)), 63));
 }
 
 // the workgroup's copy of the decoder image (built once per launch by render_init_kernel) behind the 4 wave regions
@@ -377,7 +423,7 @@ __device__ __forceinline__ void flush_depth_range(uint32_t* scal_u, int grp, flo
   }
 }
 
-__global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
+__global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec);
@@ -421,7 +467,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
     }
 
     // ---- coarse ray-march weights (63 intervals: lane i <-> samples i, i+1)
-    const float zn = __shfl_down(zc, 1, 64), sn = __shfl_down(sigc, 1, 64);
+    const float zn = lane_next(zc, zc), sn = lane_next(sigc, sigc);
     float wgt;
     {
       const float dl = zn - zc;
@@ -434,18 +480,18 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
     // ---- importance sampling (renderer.py:479-552)
     float zf;
     {
-      const float wm1 = __shfl_up(wgt, 1, 64);
+      const float wm1 = lane_prev(wgt, wgt);
       // max_pool1d(k=2,s=1,pad=1) over 63 weights -> 64 values
       const float mp = lane == 0 ? wgt : (lane == NS - 1 ? wm1 : fmaxf(wm1, wgt));
-      const float mpn = __shfl_down(mp, 1, 64);
+      const float mpn = lane_next(mp, mp);
       const float av = (mp + mpn) * 0.5f + 0.01f;           // avg_pool1d(2,1): 63 values (lanes 0..62)
       // pdf over weights[1:-1]  -> 61 values; lane k (0..60) takes av[k+1]
-      const float wk = __shfl_down(av, 1, 64) + 1e-5f;
+      const float wk = lane_next(av, av) + 1e-5f;
       const float wv = lane < NS - 3 ? wk : 0.f;
-      const float tot = wave_sum(wv);
+      const float tot = wave_total(wv);
       const float pdf = wv / tot;
       const float cdf_incl = wave_incl_sum(pdf, lane);
-      const float cdf_excl = __shfl_up(cdf_incl, 1, 64);
+      const float cdf_excl = lane_prev(cdf_incl, 0.f);
       const float cdf = lane == 0 ? 0.f : cdf_excl;          // cdf[k], k = 0..61 valid
       const float zmid = 0.5f * (zc + zn);                  // bins[k], k = 0..62 valid
       float* cdf_s = feat; float* bin_s = feat + 64;
@@ -524,8 +570,8 @@ __global__ __launch_bounds__(256, 3) void render_kernel(RenderP p) {
     float acc_b = w0 * (e[0][4] + e[1][4]) * 0.5f + w1 * (e[1][4] + e[2][4]) * 0.5f;
     float acc_d = w0 * (e[0][0] + e[1][0]) * 0.5f + w1 * (e[1][0] + e[2][0]) * 0.5f;
     float acc_w = w0 + w1;
-    acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
-    acc_d = wave_sum(acc_d); acc_w = wave_sum(acc_w);
+    acc_r = wave_total(acc_r); acc_g = wave_total(acc_g); acc_b = wave_total(acc_b);
+    acc_d = wave_total(acc_d); acc_w = wave_total(acc_w);
     dmin_l = fminf(dmin_l, fminf(zc, zf)); dmax_l = fmaxf(dmax_l, fmaxf(zc, zf));
     if (lane == 0) {
       if (p.white_back) { acc_r += 1.0f - acc_w; acc_g += 1.0f - acc_w; acc_b += 1.0f - acc_w; }

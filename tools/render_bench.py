@@ -15,7 +15,10 @@ dev = 'cuda'
 tp = Triplane(img_resolution=256).to(dev)
 tp.decoder.net[2].bias.data[0] += 4.0
 pcl = torch.randn(1, 3, 128, 128, 32, device=dev) * 4
-for res, V in ((256, 4), (128, 8), (512, 2)):
+CASES = ((256, 4), (128, 8), (512, 2))
+if len(sys.argv) > 1:
+    CASES = tuple(c for c in CASES if c[0] == int(sys.argv[1]))
+for res, V in CASES:
     cams = orbit_cameras(V).to(dev)
     idx = torch.zeros(V, dtype=torch.int32, device=dev)
     j = torch.rand(V, res * res, 64, device=dev)
