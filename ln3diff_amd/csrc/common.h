@@ -36,6 +36,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 64 lanes on the DPP cross-lane path (row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast:15 / :31 - LLVM's
+// wave64 gfx9 scan), the total broadcast from lane 63 through an SGPR: 6 VALU-rate instructions instead of 6 ds_bpermute round
+// trips through the LDS.  Summation order differs from wave_sum's butterfly (last-ulp differences).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_step(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x = dpp_add_step<0x111, 0xf>(x); x = dpp_add_step<0x112, 0xf>(x); x = dpp_add_step<0x114, 0xf>(x); x = dpp_add_step<0x118, 0xf>(x);
+  x = dpp_add_step<0x142, 0xa>(x); x = dpp_add_step<0x143, 0xc>(x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

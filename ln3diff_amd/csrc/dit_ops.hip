@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel_v8(NormP p) {
     }
   float mean = 0.f, rstd;
   if (p.kind == 0) {
-    mean = wave_sum(s) / p.D;
+    mean = wave_sum_dpp(s) / p.D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MV8; ++i)
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel_v8(NormP p) {
           q += (a * a + b * b) + (c * c + d * d);
         }
       }
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
   } else {
     float q = 0.f;
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel_v8(NormP p) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) q += (v[i][k].x * v[i][k].x + v[i][k].y * v[i][k].y) + (v[i][k].z * v[i][k].z + v[i][k].w * v[i][k].w);
       }
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
   }
   const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
   bf16_t* yr = p.y + orow * p.D;
