@@ -112,8 +112,10 @@ int ln3d_vit_assemble(const float* patch, const float* cls, const float* reg, co
                       void* stream);
 
 /* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
- * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40) */
-int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, float eps, void* stream);
+ * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40).
+ * Dh = stored row width (64 or 128); true_dim = the head size the mean is taken over when heads are zero-padded to Dh
+ * (DiT-XL: 72 in rows of 128; w then has Dh entries, zero beyond true_dim); 0 = Dh */
+int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, int true_dim, float eps, void* stream);
 
 /* ---------------------------------------------------------------- norm + modulation
  * y[r, :] = norm(x[r, :]) * (1 + scale) + shift  -> bf16, one wavefront per row, fp32 statistics.

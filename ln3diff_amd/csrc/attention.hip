@@ -847,7 +847,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
 
 // ---------------------------------------------------------------------------------------------
 // per-head RMSNorm on q / k (qk_norm): rows of Dh bf16, in place; one 16-lane group per row (Dh=64)
-__global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, int Dh, float eps) {
+__global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, int Dh, int true_dim, float eps) {
   const int per = Dh / 4;                          // lanes per row, 4 elements each
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / per;
@@ -858,7 +858,7 @@ __global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, in
   float v0 = bf2f(raw.x & 0xffff), v1 = bf2f(raw.x >> 16), v2 = bf2f(raw.y & 0xffff), v3 = bf2f(raw.y >> 16);
   float ss = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
   for (int o = per >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  const float rs = rsqrtf(ss / Dh + eps);
+  const float rs = rsqrtf(ss / true_dim + eps);
   const float4 ww = *reinterpret_cast<const float4*>(w + c * 4);
   uint2 o;
   o.x = pack2bf(v0 * rs * ww.x, v1 * rs * ww.y);
@@ -866,11 +866,12 @@ __global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, in
   *reinterpret_cast<uint2*>(px) = o;
 }
 
-extern "C" int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, float eps, void* stream) {
-  if (!x || !w || (Dh != 64 && Dh != 128)) return LN3D_ERR_BAD_ARG;
+extern "C" int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, int true_dim, float eps, void* stream) {
+  if (!x || !w || (Dh != 64 && Dh != 128) || true_dim < 0 || true_dim > Dh) return LN3D_ERR_BAD_ARG;
+  if (true_dim == 0) true_dim = Dh;
   const int per = Dh / 4;
   const int64_t threads = rows * per;
   hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (bf16_t*)x, w, rows, Dh, eps);
+                     (bf16_t*)x, w, rows, Dh, true_dim, eps);
   return ln3d_check_launch();
 }

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import ops, _cache
 from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
-                                  self_attention_hip, pad_head_columns)
+                                  self_attention_hip, pad_head_columns, attn_head_pad)
 from .dit_trilatent import DiT, DiT_TriLatent
 
 
@@ -66,7 +66,9 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             q = {}
             q['n1'], q['n2'] = f32(b.norm1.weight, device), f32(b.norm2.weight, device)
             q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
-            q['qn'], q['kn'] = f32(b.attn.q_norm.weight, device), f32(b.attn.k_norm.weight, device)
+            dh = self.embed_dim // self.num_heads
+            padw = lambda w: torch.nn.functional.pad(w.detach().float(), (0, attn_head_pad(dh) - dh))     # zero beyond the true head size
+            q['qn'], q['kn'] = f32(padw(b.attn.q_norm.weight), device), f32(padw(b.attn.k_norm.weight), device)
             q['proj_w'], q['proj_b'] = bf16(pad_head_columns(b.attn.proj.weight.detach(), self.num_heads, self.embed_dim // self.num_heads), device), f32(b.attn.proj.bias, device)
             q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
             q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
@@ -296,6 +298,10 @@ def DiT_L_Pixelart_MV_2(**kwargs):
     return DiT_I23D_PixelArt_MVCond(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
 
 
+def DiT_XL_Pixelart_MV_2(**kwargs):       # reference dit_i23d.py:659-664; head size 72 runs in zero-padded 128-wide heads
+    return DiT_I23D_PixelArt_MVCond(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+
+
 def DiT_B_Pixelart_MV_2(**kwargs):
     return DiT_I23D_PixelArt_MVCond(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
 
@@ -311,4 +317,4 @@ def DiT_B_Pixelart_2(**kwargs):
 DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
               # reference registry (dit_i23d.py:686-696): 'MV-L/2' is the no-CLIP class, 'MV-B/2' the CLIP+DINO one
               'DiT-PixArt-MV-L/2': DiT_L_Pixelart_MV_2_noclip, 'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2,
-              'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2}
+              'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2, 'DiT-PixArt-MV-XL/2': DiT_XL_Pixelart_MV_2}

@@ -221,7 +221,6 @@ def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=No
     produce 0 output columns, which meet zero columns of the padded proj weight)."""
     Dh = D // H
     Dp = attn_head_pad(Dh)
-    assert qn is None or Dp == Dh
     nq = N if nq is None else nq
     npad = (N + 63) // 64 * 64
     q = ws.get(tag + 'q', (B, H, npad, Dp), torch.bfloat16, zero=True)
@@ -231,8 +230,8 @@ def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=No
     ops.gemm(h_bf16, qkv_w, qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
              transpose_mask=0b100, head_dim_pad=Dp)
     if qn is not None:
-        ops.rmsnorm_heads(q, qn, B * H * npad, Dh)
-        ops.rmsnorm_heads(k, kn, B * H * npad, Dh)
+        ops.rmsnorm_heads(q, qn, B * H * npad, Dp, true_dim=Dh)      # qn / kn: [Dp] (zero beyond Dh when padded)
+        ops.rmsnorm_heads(k, kn, B * H * npad, Dp, true_dim=Dh)
     ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dp, scale=Dh ** -0.5)
     return o
 

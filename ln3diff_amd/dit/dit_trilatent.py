@@ -299,4 +299,8 @@ def DiT_B_2(**kwargs):
     return DiT_TriLatent(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
 
 
-DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2}
+def DiT_B_1(**kwargs):          # reference dit_trilatent.py:296-301: no spatial compression, 3 x 1024 tokens per sample
+    return DiT_TriLatent(depth=12, hidden_size=768, patch_size=1, num_heads=12, **kwargs)
+
+
+DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2, 'DiT-B/1': DiT_B_1}

@@ -58,8 +58,9 @@ def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causa
     L.check(L.lib().ln3d_attention_bf16(C.byref(a), _stream()), "attention")
 
 
-def rmsnorm_heads(x, w, rows, Dh, eps=1e-5):
-    L.check(L.lib().ln3d_rmsnorm_heads_bf16(_p(x), _p(w), C.c_int64(rows), Dh, C.c_float(eps), _stream()), "rmsnorm_heads")
+def rmsnorm_heads(x, w, rows, Dh, eps=1e-5, true_dim=0):
+    """x rows of Dh (64 / 128) bf16 in place; true_dim < Dh when heads are zero-padded (w padded with zeros to Dh)."""
+    L.check(L.lib().ln3d_rmsnorm_heads_bf16(_p(x), _p(w), C.c_int64(rows), Dh, int(true_dim), C.c_float(eps), _stream()), "rmsnorm_heads")
 
 
 def norm_modulate(x, y, rows, D, kind=0, eps=1e-6, weight=None, shift=None, scale=None, mod_rows=1, mod_ld=0,

@@ -38,6 +38,7 @@ DIT_CONFIGS = {
     "DiT-B/2": (768, 12, 12),
     "DiT-L/2": (1024, 24, 16),
     "DiT-XL/2": (1152, 28, 16),
+    "DiT-B/1": (768, 12, 12),        # patch size 1 (pass patch=1 to t23d_forward)
 }
 
 

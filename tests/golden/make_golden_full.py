@@ -160,7 +160,42 @@ def sec_chain():
          grid_sigma=grid['sigma'], grid_rgb=grid['rgb'], cams=cams, z_seed=np.array(41), jitter_seed=np.array(0))
 
 
-SECTIONS = {'full_edm': sec_full_edm, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain}
+def sec_f4():
+    print('== f4 registry variants: DiT-B/1 (T23D, patch 1) and DiT-PixArt-MV-XL/2 (MVCond, head size 72)')
+    from dit.dit_trilatent import DiT_models as REF_T
+    from dit.dit_models_xformers import TextCondDiTBlock
+    from dit.dit_i23d import DiT_models as REF_I
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = REF_T['DiT-B/1'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                             vit_blk=TextCondDiTBlock).eval()
+    sd, shapes = load_synth(m, 0)
+    x = synth_input('x', (1, 12, 32, 32), 0)
+    t = torch.tensor([500.])
+    ctx = synth_input('ctx', (1, 77, 768), 0)
+    t0 = time.time()
+    y_ref = m(x, t, ctx)
+    y_or = odit.t23d_forward(sd, x, t, ctx, 12, patch=1)
+    check('DiT-B/1 forward', y_or, y_ref)
+    save('t23d_dit_b1', y=y_ref, t=t, manifest=mg.manifest_json(shapes))
+    print(f'  (DiT-B/1: {time.time() - t0:.1f}s)')
+    del m, sd
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = REF_I['DiT-PixArt-MV-XL/2'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                                        pooling_ctx_dim=768).eval()
+    sd, shapes = load_synth(m, 0)
+    x = synth_input('x', (2, 12, 32, 32), 5)
+    t = torch.tensor([0.4, 0.7])
+    ctx = {'crossattn': synth_input('ca', (2, 256, 1024), 5), 'vector': synth_input('v', (2, 768), 5),
+           'concat': synth_input('mv', (2, 4, 256, 768), 5)}
+    t0 = time.time()
+    y_ref = m(x, t, ctx)
+    y_or = odit.i23d_mv_forward(sd, x, t, ctx, 16)
+    check('DiT-PixArt-MV-XL/2 forward', y_or, y_ref)
+    save('i23d_mv_xl2', y=y_ref, t=t, manifest=mg.manifest_json(shapes))
+    print(f'  (MV-XL/2: {time.time() - t0:.1f}s)')
+
+
+SECTIONS = {'full_edm': sec_full_edm, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain, 'f4': sec_f4}
 
 if __name__ == '__main__':
     for s in (sys.argv[1:] or list(SECTIONS)):

@@ -38,7 +38,7 @@ def test_t23d_tiny_vs_golden_and_oracle(hip_lib):
 
 
 @pytest.mark.parametrize("arch,B,tag", [('DiT-B/2', 1, 't23d_dit_b2'), ('DiT-L/2', 2, 't23d_dit_l2'),
-                                        ('DiT-XL/2', 1, 't23d_dit_xl2')])
+                                        ('DiT-XL/2', 1, 't23d_dit_xl2'), ('DiT-B/1', 1, 't23d_dit_b1')])
 def test_t23d_full_vs_golden(hip_lib, arch, B, tag):
     from ln3diff_amd.dit.dit_trilatent import DiT_models
     from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
@@ -49,7 +49,7 @@ def test_t23d_full_vs_golden(hip_lib, arch, B, tag):
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
     load_synth(m, 0)
     x = synth_input('x', (B, 12, 32, 32), 0)
-    t = torch.tensor([500., 999.][:B])
+    t = torch.from_numpy(g['t']).float()
     ctx = synth_input('ctx', (B, 77, 768), 0)
     m = m.cuda()
     y = m(x.cuda(), t.cuda(), ctx.cuda()).cpu()

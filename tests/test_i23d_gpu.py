@@ -151,3 +151,23 @@ def test_i23d_multiview_noclip_variant_vs_reference_golden(hip_lib):
     e = rel_l2(y, g['y'])
     print('i23d MVCond_noClip tiny', e)
     assert e < 2e-2, e
+
+
+def test_i23d_mv_xl2_registry_vs_reference_golden(hip_lib):
+    """'DiT-PixArt-MV-XL/2' (dit_i23d.py:659-664): MVCond at hidden 1152 / 16 heads - head size 72 in zero-padded 128-wide heads,
+    qk-norm over the true 72 dims."""
+    from ln3diff_amd.dit.dit_i23d import DiT_models
+    from ln3diff_amd.synth import synth_input
+    g = golden('i23d_mv_xl2')
+    m = DiT_models['DiT-PixArt-MV-XL/2'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                                         pooling_ctx_dim=768)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (2, 12, 32, 32), 5).cuda()
+    ctx = {'crossattn': synth_input('ca', (2, 256, 1024), 5).cuda(), 'vector': synth_input('v', (2, 768), 5).cuda(),
+           'concat': synth_input('mv', (2, 4, 256, 768), 5).cuda()}
+    y = m(x, torch.from_numpy(g['t']).cuda(), ctx).cpu()
+    e = rel_l2(y, g['y'])
+    print('i23d MV-XL/2', e)
+    assert e < 2e-2, e
