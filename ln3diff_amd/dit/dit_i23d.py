@@ -45,9 +45,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         from .dit_models_xformers import Workspace
         D = self.embed_dim
         P = {'device': device}
-        P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
-        P['pe_b'] = f32(self.x_embedder.proj.bias, device)
-        P['pos'] = f32(self.pos_embed[0], device)
+        self._pack_embedder(P, device)
         P['t_w0'], P['t_b0'] = bf16(self.t_embedder.mlp[0].weight, device), f32(self.t_embedder.mlp[0].bias, device)
         P['t_w2'], P['t_b2'] = bf16(self.t_embedder.mlp[2].weight, device), f32(self.t_embedder.mlp[2].bias, device)
         P['ada_w'], P['ada_b'] = bf16(self.adaLN_modulation[1].weight, device), f32(self.adaLN_modulation[1].bias, device)
@@ -83,6 +81,12 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P['zeros'] = torch.zeros(max(D, self.pooling_ctx_dim), device=device)
         self._packed = _cache.stamp(P)
         self._ws = Workspace(device)
+
+    def _pack_embedder(self, P, device):
+        D = self.embed_dim
+        P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
+        P['pe_b'] = f32(self.x_embedder.proj.bias, device)
+        P['pos'] = f32(self.pos_embed[0], device)
 
     def _cls_token(self, vec):
         """pooled token: LayerNorm(affine, eps 1e-5) -> Linear   (dit_i23d.py:211-217,245)"""
@@ -165,7 +169,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         Bn, Bx = timesteps.shape[0], x.shape[0]
         assert cc['Bn'] == Bn
         S, p, C = self.input_size, self.patch_size, self.in_channels
-        N = 3 * (S // p) ** 2
+        N = self._num_tokens(x)
         Ld = cc['dino'].shape[1]
         NA = N + Ld
         M = Bn * N
@@ -185,8 +189,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         mod = ws.get('modb', (depth, Bn, 6 * D), torch.float32)
         ops.add_table_rows(t0, P['sst'], mod, depth, Bn, 6 * D)
 
-        xt = ws.get('x', (M, D), torch.float32)
-        ops.patch_embed(x.contiguous().float(), in_scale, P['pe_w'], P['pe_b'], P['pos'], xt, Bx, Bn, C, S, p, D)
+        xt = self._embed_tokens(x, in_scale, Bx, Bn, N)
         ha = ws.get('ha', (Bn, NA, D), torch.bfloat16)
         if getattr(self, '_ha_src', None) is not cc['dino'] or getattr(self, '_ha_buf', None) is not ha:
             ha[:, N:].copy_(cc['dino'])                                # appended DINO tokens: constant per prompt, and the
@@ -219,9 +222,26 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             else:
                 ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=mi[:, 5 * D:], gate_rows=N, gate_ld=ld)
-        out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)
+        return self._output(xt, tsum, Bn, N)
+
+    # ---- the two ends of forward that the point-cloud variant replaces
+    def _num_tokens(self, x):
+        return 3 * (self.input_size // self.patch_size) ** 2
+
+    def _embed_tokens(self, x, in_scale, Bx, Bn, N):
+        """patchify + shared conv patch-embed + positional embedding -> fp32 tokens [Bn*N, D]"""
+        P, D = self._packed, self.embed_dim
+        xt = self._ws.get('x', (Bn * N, D), torch.float32)
+        ops.patch_embed(x.contiguous().float(), in_scale, P['pe_w'], P['pe_b'], P['pos'], xt, Bx, Bn, self.in_channels, self.input_size,
+                        self.patch_size, D)
+        return xt
+
+    def _output(self, xt, tsum, Bn, N):
+        """T2IFinalLayer (LN, scale_shift_table + t, Linear) + unpatchify -> [Bn, 3*C_out, S, S]"""
+        P, D, S = self._packed, self.embed_dim, self.input_size
+        out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=xt.device)
         ops.final_layer(xt, tsum, tsum, D, P['fin_sst'][0], P['fin_sst'][1], P['fin_w'], P['fin_b'], out, Bn,
-                        self.out_channels, S, p, D)
+                        self.out_channels, S, self.patch_size, D)
         return out
 
     @torch.no_grad()
@@ -290,6 +310,68 @@ class DiT_I23D_PixelArt_MVCond_noClip(DiT_I23D_PixelArt):
                 'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
 
 
+class DiT_pcd_I23D_PixelArt_MVCond(DiT_I23D_PixelArt_MVCond):
+    """Point-cloud latent variant (reference dit/dit_i23d.py:500-588; registry key 'DiT-PixArt-MV-PCD-L'): the tokens are the N
+    points of x [B, N, in_channels]; x_embedder is a timm Mlp (Linear -> tanh-GELU -> Linear) instead of the conv patch-embed,
+    there is no positional embedding and no unpatchify - the output is [B, N, out_channels].  Conditioning and blocks as MVCond.
+    On the HIP path the embedder runs as two GEMMs with the input channels zero-padded to the GEMM's K granule, and the final
+    Linear as a bf16 GEMM (the output width is padded to a multiple of 4 and sliced)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        from .dit_models_xformers import Mlp
+        self.x_embedder = Mlp(self.in_channels, self.embed_dim, self.embed_dim)
+        del self.pos_embed
+
+    def _pack_embedder(self, P, device):
+        C, D = self.in_channels, self.embed_dim
+        kp = (C + 63) // 64 * 64
+        w1 = torch.zeros(D, kp)
+        w1[:, :C] = self.x_embedder.fc1.weight.detach().float().cpu()
+        P['xe_w1'], P['xe_b1'] = bf16(w1, device), f32(self.x_embedder.fc1.bias, device)
+        P['xe_w2'], P['xe_b2'] = bf16(self.x_embedder.fc2.weight, device), f32(self.x_embedder.fc2.bias, device)
+        P['xe_kpad'] = kp
+        co = self.final_layer.linear.weight.shape[0]
+        cp = (co + 3) // 4 * 4
+        fw = torch.zeros(cp, D)
+        fw[:co] = self.final_layer.linear.weight.detach().float().cpu()
+        fb = torch.zeros(cp)
+        fb[:co] = self.final_layer.linear.bias.detach().float().cpu()
+        P['finp_w'], P['finp_b'], P['finp_n'] = bf16(fw, device), f32(fb, device), co
+
+    def _num_tokens(self, x):
+        return x.shape[1]
+
+    def _embed_tokens(self, x, in_scale, Bx, Bn, N):
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        assert x.dim() == 3 and x.shape[2] == self.in_channels, "point-cloud latent [B, N, in_channels]"
+        xin = x.float()
+        if in_scale is not None:                       # c_in of a denoiser wrapper, one factor per network row
+            xin = xin.repeat(Bn // Bx, 1, 1) * in_scale.view(-1, 1, 1)
+        elif Bn != Bx:
+            xin = xin.repeat(Bn // Bx, 1, 1)
+        xb = ws.get('pcd_in', (Bn * N, P['xe_kpad']), torch.bfloat16, zero=True)
+        xb[:, :self.in_channels] = xin.reshape(Bn * N, self.in_channels).to(torch.bfloat16)
+        h1 = ws.get('pcd_h', (Bn * N, D), torch.bfloat16)
+        ops.gemm(xb, P['xe_w1'], P['xe_b1'], ops.EPI_GELU_TANH, h1)
+        xt = ws.get('x', (Bn * N, D), torch.float32)
+        ops.gemm(h1, P['xe_w2'], P['xe_b2'], ops.EPI_F32, xt)
+        return xt
+
+    def _output(self, xt, tsum, Bn, N):
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        yb = ws.get('pcd_fin', (Bn * N, D), torch.bfloat16)
+        ops.norm_modulate(xt, yb, Bn * N, D, kind=0, eps=1e-6, shift=tsum, scale=tsum, mod_rows=N, mod_ld=D,
+                          shift_table=P['fin_sst'][0], scale_table=P['fin_sst'][1])
+        out = torch.empty(Bn * N, P['finp_w'].shape[0], device=xt.device, dtype=torch.float32)
+        ops.gemm(yb, P['finp_w'], P['finp_b'], ops.EPI_F32, out)
+        return out[:, :P['finp_n']].reshape(Bn, N, P['finp_n']).contiguous()
+
+
+def DiT_L_Pixelart_MV_pcd(**kwargs):          # reference dit_i23d.py:675-681
+    return DiT_pcd_I23D_PixelArt_MVCond(depth=24, hidden_size=1024, patch_size=1, num_heads=16, **kwargs)
+
+
 def DiT_L_Pixelart_MV_2_noclip(**kwargs):
     return DiT_I23D_PixelArt_MVCond_noClip(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
 
@@ -317,4 +399,5 @@ def DiT_B_Pixelart_2(**kwargs):
 DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
               # reference registry (dit_i23d.py:686-696): 'MV-L/2' is the no-CLIP class, 'MV-B/2' the CLIP+DINO one
               'DiT-PixArt-MV-L/2': DiT_L_Pixelart_MV_2_noclip, 'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2,
-              'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2, 'DiT-PixArt-MV-XL/2': DiT_XL_Pixelart_MV_2}
+              'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2, 'DiT-PixArt-MV-XL/2': DiT_XL_Pixelart_MV_2,
+              'DiT-PixArt-MV-PCD-L': DiT_L_Pixelart_MV_pcd}

@@ -281,6 +281,29 @@ def i23d_mv_forward(sd, x, timesteps, context, num_heads, patch=2):
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
 
+def i23d_pcd_forward(sd, x, timesteps, context, num_heads):
+    """DiT_pcd_I23D_PixelArt_MVCond.forward (dit/dit_i23d.py:500-588, registry key 'DiT-PixArt-MV-PCD-L'): the tokens are the
+    points of a point-cloud latent x [B, N, C] - no patchify, no positional embedding; x_embedder is a timm Mlp
+    (Linear -> tanh-GELU -> Linear); conditioning and blocks as MVCond; the output stays [B, N, out_channels]."""
+    B = x.shape[0]
+    depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    vec = context['vector'].float()
+    cls = linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
+                 sd['cap_embedder.1.weight'], sd['cap_embedder.1.bias'])
+    clip_tok = caption_embedder(sd, 'clip_spatial_proj.', context['crossattn'].float())
+    mv = context['concat'].float()
+    dino_tok = mv.reshape(B, mv.shape[1] * mv.shape[2], mv.shape[3])
+    t = t_embedder(sd, timesteps.float()) + cls
+    t0 = linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    h = linear(x.float(), sd['x_embedder.fc1.weight'], sd['x_embedder.fc1.bias'])
+    h = linear(F.gelu(h, approximate='tanh'), sd['x_embedder.fc2.weight'], sd['x_embedder.fc2.bias'])
+    for i in range(depth):
+        h = i23d_block(sd, f'blocks.{i}.', h, t0, clip_tok, dino_tok, num_heads)
+    shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
+    y = layer_norm(h) * (1 + scale) + shift
+    return linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias']).float()
+
+
 def i23d_mv_noclip_forward(sd, x, timesteps, context, num_heads, patch=2):
     """DiT_I23D_PixelArt_MVCond_noClip.forward (dit/dit_i23d.py:387-492, the class the reference registers as
     'DiT-PixArt-MV-L/2'): no CLIP branch at all - t = t_embedder(timesteps), nothing is appended to the self-attention

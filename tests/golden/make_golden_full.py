@@ -193,6 +193,25 @@ def sec_f4():
     check('DiT-PixArt-MV-XL/2 forward', y_or, y_ref)
     save('i23d_mv_xl2', y=y_ref, t=t, manifest=mg.manifest_json(shapes))
     print(f'  (MV-XL/2: {time.time() - t0:.1f}s)')
+    del m, sd
+    # point-cloud latent variant: tiny (class semantics) and the registry size ('DiT-PixArt-MV-PCD-L': depth 24, hidden 1024)
+    from dit.dit_i23d import DiT_pcd_I23D_PixelArt_MVCond
+    for tag, kw, heads in (('tiny', dict(hidden_size=128, depth=2, num_heads=2, patch_size=1), 2), ('l', None, 16)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            if kw is None:
+                m = REF_I['DiT-PixArt-MV-PCD-L'](input_size=32, num_classes=0, learn_sigma=False, in_channels=19, context_dim=768,
+                                                 roll_out=True, pooling_ctx_dim=768).eval()
+            else:
+                m = DiT_pcd_I23D_PixelArt_MVCond(input_size=32, num_classes=0, learn_sigma=False, in_channels=19, context_dim=768,
+                                                 roll_out=True, pooling_ctx_dim=768, **kw).eval()
+        sd, shapes = load_synth(m, 0)
+        x = synth_input('pcd', (2, 768, 19), 7)
+        t = torch.tensor([0.4, 0.7])
+        y_ref = m(x, t, ctx)
+        y_or = odit.i23d_pcd_forward(sd, x, t, ctx, heads)
+        check(f'DiT_pcd_I23D_PixelArt_MVCond {tag} forward', y_or, y_ref)
+        save(f'i23d_pcd_{tag}', y=y_ref, t=t, manifest=mg.manifest_json(shapes))
+        del m, sd
 
 
 SECTIONS = {'full_edm': sec_full_edm, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain, 'f4': sec_f4}

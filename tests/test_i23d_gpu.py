@@ -171,3 +171,26 @@ def test_i23d_mv_xl2_registry_vs_reference_golden(hip_lib):
     e = rel_l2(y, g['y'])
     print('i23d MV-XL/2', e)
     assert e < 2e-2, e
+
+
+@pytest.mark.parametrize("tag", ['tiny', 'l'])
+def test_i23d_pcd_variant_vs_reference_golden(hip_lib, tag):
+    """DiT_pcd_I23D_PixelArt_MVCond / 'DiT-PixArt-MV-PCD-L' (dit_i23d.py:500-588): point tokens, Mlp embedder, no positional
+    embedding, output [B, N, C]."""
+    from ln3diff_amd.dit.dit_i23d import DiT_models, DiT_pcd_I23D_PixelArt_MVCond
+    from ln3diff_amd.synth import synth_input
+    g = golden(f'i23d_pcd_{tag}')
+    kw = dict(input_size=32, num_classes=0, learn_sigma=False, in_channels=19, context_dim=768, roll_out=True, pooling_ctx_dim=768)
+    m = DiT_models['DiT-PixArt-MV-PCD-L'](**kw) if tag == 'l' else \
+        DiT_pcd_I23D_PixelArt_MVCond(hidden_size=128, depth=2, num_heads=2, patch_size=1, **kw)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('pcd', (2, 768, 19), 7).cuda()
+    ctx = {'crossattn': synth_input('ca', (2, 256, 1024), 5).cuda(), 'vector': synth_input('v', (2, 768), 5).cuda(),
+           'concat': synth_input('mv', (2, 4, 256, 768), 5).cuda()}
+    y = m(x, torch.from_numpy(g['t']).cuda(), ctx).cpu()
+    assert y.shape == (2, 768, 19)
+    e = rel_l2(y, g['y'])
+    print('i23d pcd', tag, e)
+    assert e < 2e-2, e
