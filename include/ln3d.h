@@ -250,10 +250,16 @@ int ln3d_query_points(const float* planes, int H, int W, const float* points, in
 
 /* ---------------------------------------------------------------- iso-surface of the sigma grid (mesh export)
  * Replaces mcubes.marching_cubes(sigma[G,G,G], thr) at nsr/train_util_diffusion.py:221 (PyMCubes, third-party, absent:
- * parity unpinned) with marching tetrahedra.  Pass 1: triangles per cell -> counts[(G-1)^3] (cell = (x*(G-1)+y)*(G-1)+z);
+ * parity unpinned) with marching tetrahedra (ln3d_mesh_*) or classic marching cubes (ln3d_mcubes_*, the default of the drivers).  Pass 1: triangles per cell -> counts[(G-1)^3] (cell = (x*(G-1)+y)*(G-1)+z);
  * caller takes the inclusive prefix sum; pass 2 writes for triangle k its 3 vertices (grid coordinates) to
  * tri_pos[k*9..] and the ids of the grid edges they lie on to tri_key[k*3..] (for welding).                          */
 int ln3d_mesh_count(const float* sigma, int G, float thr, int32_t* counts, void* stream);
+/* Same two passes for CLASSIC marching cubes (Lorensen & Cline - the algorithm of mcubes.marching_cubes; 256-case table
+ * csrc/mc_table.h, <= 5 triangles per cell, corner value > thr = inside).  Pinned against scikit-image's classic implementation
+ * (tests/golden/mcubes_classic.npz); PyMCubes itself is absent. */
+int ln3d_mcubes_count(const float* sigma, int G, float thr, int32_t* counts, void* stream);
+int ln3d_mcubes_emit(const float* sigma, int G, float thr, const int64_t* offsets_inclusive, float* tri_pos, int64_t* tri_key,
+                     void* stream);
 int ln3d_mesh_emit(const float* sigma, int G, float thr, const int64_t* offsets_inclusive, float* tri_pos, int64_t* tri_key,
                    void* stream);
 

@@ -1,11 +1,15 @@
 // Iso-surface extraction on the sigma grid for gfx950 (the "mesh" step of the sampling drivers:
 // nsr/train_util_diffusion.py:208-248 calls PyMCubes 0.1.4 `marching_cubes(sigma[G,G,G], thr)`, a third-party package
-// absent from the reference tree: parity is unpinned).  This is marching TETRAHEDRA on the Kuhn decomposition of each cell
+// absent from the reference tree: parity with PyMCubes itself is unpinned).  Two extractors share the count / emit passes:
+//  * classic marching CUBES (Lorensen & Cline, the algorithm mcubes implements): 256-case triangle table mc_table.h, pinned
+//    against scikit-image's classic implementation (tools/gen_mc_table.py, tests/golden/mcubes_classic.npz) - the default;
+//  * marching TETRAHEDRA (round 1; no ambiguous cases, watertight by construction) on the Kuhn decomposition of each cell
 // (6 tetrahedra around the 0-7 diagonal; face-consistent across cells, no 256-case table): every tetrahedron emits 0, 1
 // or 2 triangles; vertices are identified by the grid edge they lie on (key = min_vertex_id * G^3 + max_vertex_id), so the
 // host welds them with one unique() and no floating-point comparison.  Two passes (count, emit) around a prefix sum.
 #include "common.h"
 #include "../../include/ln3d.h"
+#include "mc_table.h"
 
 __constant__ int kTet[6][4] = {{0, 1, 3, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 6, 7}, {0, 4, 5, 7}, {0, 1, 5, 7}};
 
@@ -92,6 +96,57 @@ __global__ void mesh_emit_kernel(MeshP p, int64_t ncell, const int64_t* offsets,
       ++o;
     }
   }
+}
+
+// ------------------------------------------------------------------ classic marching cubes
+__device__ __forceinline__ int mc_case(const MeshP& p, const float v[8]) {
+  int cs = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cs |= (v[c] > p.thr) << c;
+  return cs;
+}
+__global__ void mcubes_count_kernel(MeshP p, int64_t ncell, int32_t* counts) {
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell) return;
+  float v[8]; int64_t gid[8]; int cx, cy, cz;
+  cell_corners(p, cell, v, gid, cx, cy, cz);
+  counts[cell] = kMcCount[mc_case(p, v)];
+}
+__global__ void mcubes_emit_kernel(MeshP p, int64_t ncell, const int64_t* offsets, float* tri_pos, int64_t* tri_key) {
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell) return;
+  float v[8]; int64_t gid[8]; int cx, cy, cz;
+  cell_corners(p, cell, v, gid, cx, cy, cz);
+  const int cs = mc_case(p, v);
+  const int nt = kMcCount[cs];
+  int64_t o = cell == 0 ? 0 : offsets[cell - 1];
+  for (int t = 0; t < nt; ++t, ++o)
+    for (int j = 0; j < 3; ++j) {
+      const int e = kMcTri[cs][3 * t + j];
+      const int ax = e >> 2, b0 = e & 1, b1 = (e >> 1) & 1;
+      // edge parallel to axis ax; its other two coordinates (in axis order) are (b0, b1)
+      const int a = ax == 0 ? (b0 << 1) | (b1 << 2) : (ax == 1 ? b0 | (b1 << 2) : b0 | (b1 << 1));
+      const int b = a | (1 << ax);
+      float q[3]; int64_t key;
+      edge_point(p, v, gid, cx, cy, cz, a, b, q, key);
+      tri_pos[(o * 3 + j) * 3 + 0] = q[0]; tri_pos[(o * 3 + j) * 3 + 1] = q[1]; tri_pos[(o * 3 + j) * 3 + 2] = q[2];
+      tri_key[o * 3 + j] = key;
+    }
+}
+
+extern "C" int ln3d_mcubes_count(const float* sigma, int G, float thr, int32_t* counts, void* stream) {
+  if (!sigma || !counts || G < 2) return LN3D_ERR_BAD_ARG;
+  MeshP p{sigma, G, thr};
+  const int64_t ncell = (int64_t)(G - 1) * (G - 1) * (G - 1);
+  hipLaunchKernelGGL(mcubes_count_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, ncell, counts);
+  return ln3d_check_launch();
+}
+extern "C" int ln3d_mcubes_emit(const float* sigma, int G, float thr, const int64_t* offsets, float* tri_pos, int64_t* tri_key, void* stream) {
+  if (!sigma || !offsets || !tri_pos || !tri_key || G < 2) return LN3D_ERR_BAD_ARG;
+  MeshP p{sigma, G, thr};
+  const int64_t ncell = (int64_t)(G - 1) * (G - 1) * (G - 1);
+  hipLaunchKernelGGL(mcubes_emit_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, ncell, offsets, tri_pos, tri_key);
+  return ln3d_check_launch();
 }
 
 extern "C" int ln3d_mesh_count(const float* sigma, int G, float thr, int32_t* counts, void* stream) {

@@ -1,6 +1,8 @@
 """Mesh extraction from the sigma grid (the export_mesh branch of render_video_given_triplane,
 nsr/train_util_diffusion.py:208-248): iso-surface at sigma = 10 on the G^3 grid, vertices mapped to the +-0.45 box,
-coloured by re-querying the tri-plane, rotated -90 degrees about x, written as .obj with per-vertex colours."""
+coloured by re-querying the tri-plane, rotated -90 degrees about x, written as .obj with per-vertex colours.
+The surface is classic marching cubes (what the reference's `mcubes.marching_cubes` is; method='cubes', the default) or marching
+tetrahedra (method='tetra'); both run on the GPU in two passes around a prefix sum and weld vertices by grid-edge id."""
 import math
 
 import numpy as np
@@ -10,21 +12,23 @@ from . import ops
 
 
 @torch.no_grad()
-def extract_isosurface(sigma, thr=10.0):
-    """sigma [G,G,G] f32 device -> (verts [Nv,3] in grid coordinates, faces [Nf,3] int64)."""
+def extract_isosurface(sigma, thr=10.0, method='cubes'):
+    """sigma [G,G,G] f32 device -> (verts [Nv,3] in grid coordinates, faces [Nf,3] int64).  Faces keep the emission order
+    (cells in x-major order, the case table's triangle order inside a cell)."""
+    count, emit = {'cubes': (ops.mcubes_count, ops.mcubes_emit), 'tetra': (ops.mesh_count, ops.mesh_emit)}[method]
     G = sigma.shape[0]
     dev = sigma.device
     sigma = sigma.contiguous().float()
     ncell = (G - 1) ** 3
     counts = torch.empty(ncell, dtype=torch.int32, device=dev)
-    ops.mesh_count(sigma, G, thr, counts)
+    count(sigma, G, thr, counts)
     offs = torch.cumsum(counts.long(), 0)
     ntri = int(offs[-1])
     if ntri == 0:
         return torch.zeros(0, 3, device=dev), torch.zeros(0, 3, dtype=torch.long, device=dev)
     pos = torch.empty(ntri * 3, 3, device=dev)
     key = torch.empty(ntri * 3, dtype=torch.int64, device=dev)
-    ops.mesh_emit(sigma, G, thr, offs, pos, key)
+    emit(sigma, G, thr, offs, pos, key)
     uniq, inv = torch.unique(key, return_inverse=True)                # weld by grid-edge id
     verts = torch.empty(uniq.shape[0], 3, device=dev)
     verts[inv] = pos                                                   # identical bits for every copy of a vertex
@@ -48,12 +52,12 @@ def write_obj(path, v, f, c):
 
 
 @torch.no_grad()
-def mesh_from_grid(decoder, dec_out, sigma, grid_size, thr=10.0, sample_index=0, path=None):
+def mesh_from_grid(decoder, dec_out, sigma, grid_size, thr=10.0, sample_index=0, path=None, method='cubes'):
     """nsr/train_util_diffusion.py:221-244: iso-surface of the sigma grid at `thr`, vertices mapped to the +-0.45 box, coloured
     by re-querying the tri-plane at the vertices (forward_points), rotated -90 degrees about x.
     Returns (verts [Nv,3] float32 numpy, faces [Nf,3] int64 numpy, colors [Nv,3] uint8 numpy); writes `path` when given."""
     sigma = sigma.reshape(grid_size, grid_size, grid_size)
-    verts, faces = extract_isosurface(sigma, thr)
+    verts, faces = extract_isosurface(sigma, thr, method)
     vtx = (verts / (grid_size - 1) * 2 - 1) * 0.45                       # g-objaverse scale
     pcl = dec_out.get('planes_channel_last')
     if pcl is None:

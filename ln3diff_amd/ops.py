@@ -195,6 +195,14 @@ def mesh_emit(sigma, G, thr, offsets, tri_pos, tri_key):
     L.check(L.lib().ln3d_mesh_emit(_p(sigma), G, C.c_float(thr), _p(offsets), _p(tri_pos), _p(tri_key), _stream()), "mesh_emit")
 
 
+def mcubes_count(sigma, G, thr, counts):
+    L.check(L.lib().ln3d_mcubes_count(_p(sigma), G, C.c_float(thr), _p(counts), _stream()), "mcubes_count")
+
+
+def mcubes_emit(sigma, G, thr, offsets, tri_pos, tri_key):
+    L.check(L.lib().ln3d_mcubes_emit(_p(sigma), G, C.c_float(thr), _p(offsets), _p(tri_pos), _p(tri_key), _stream()), "mcubes_emit")
+
+
 def lincomb(y, ks, cs, out):
     n = len(ks)
     arr_k = (C.c_void_p * n)(*[k.data_ptr() for k in ks])

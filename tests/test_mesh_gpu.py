@@ -1,5 +1,7 @@
-"""Iso-surface extraction (marching tetrahedra): analytic checks on a sphere - closed manifold (every edge shared by
-exactly two triangles, Euler characteristic 2), outward orientation, vertices on the iso-level, area ~ 4 pi r^2."""
+"""Iso-surface extraction.  Classic marching cubes against golden meshes produced by scikit-image's classic (Lorensen & Cline)
+implementation in the build container (tools/gen_mc_table.py: a smooth random field with ambiguous cells, an off-centre sphere):
+the same triangles, in the same orientation, to 1e-4 of a cell.  Both extractors: analytic checks on a sphere - closed manifold
+(every edge shared by exactly two triangles, Euler characteristic 2), outward orientation, vertices on the iso-level, area."""
 import math
 
 import pytest
@@ -8,16 +10,45 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_sphere_isosurface(hip_lib):
+def _canon(tri):
+    """[T,3,3] triangle soup -> rotation-normalised (smallest vertex first, orientation kept), lexicographically sorted rows."""
+    import numpy as np
+    t = np.round(np.asarray(tri, dtype=np.float64), 4)
+    out = np.empty_like(t)
+    for i, tr in enumerate(t):
+        k = min(range(3), key=lambda j: tuple(tr[j]))
+        out[i] = np.roll(tr, -k, axis=0)
+    flat = out.reshape(len(out), 9)
+    return flat[np.lexsort(flat.T[::-1])]
+
+
+@pytest.mark.parametrize("name", ["field", "sphere"])
+def test_marching_cubes_vs_classic_golden(hip_lib, name):
+    import numpy as np
+    from conftest import golden
+    from ln3diff_amd.mesh import extract_isosurface
+    g = golden('mcubes_classic')
+    sigma = torch.from_numpy(g[name + '_sigma']).cuda()
+    v, f = extract_isosurface(sigma, float(g[name + '_level']), method='cubes')
+    tri = v[f].cpu().numpy()
+    ref = g[name + '_tri']
+    assert tri.shape == ref.shape, (tri.shape, ref.shape)
+    assert v.shape[0] == int(g[name + '_nverts'])                      # welded by grid edge: the same vertex count
+    a, b = _canon(tri), _canon(ref)
+    assert np.abs(a - b).max() < 2e-4, np.abs(a - b).max()            # same triangles, same winding
+
+
+@pytest.mark.parametrize("method", ["tetra", "cubes"])
+def test_sphere_isosurface(hip_lib, method):
     from ln3diff_amd.mesh import extract_isosurface
     G, r = 48, 15.3
     ax = torch.arange(G, dtype=torch.float32) - (G - 1) / 2 + 0.123
     X, Y, Z = torch.meshgrid(ax, ax + 0.05, ax - 0.07, indexing='ij')
     d = torch.sqrt(X * X + Y * Y + Z * Z)
     sigma = (10.0 + (r - d)).cuda()                  # > 10 inside the sphere
-    v, f = extract_isosurface(sigma, 10.0)
+    v, f = extract_isosurface(sigma, 10.0, method=method)
     v, f = v.cpu(), f.cpu()
-    assert f.shape[0] > 1000
+    assert f.shape[0] > (1000 if method == 'tetra' else 400)
     # vertices lie on the iso-level of the (trilinear) field: distance to centre ~ r
     c = torch.tensor([(G - 1) / 2 - 0.123, (G - 1) / 2 - 0.123 - 0.05, (G - 1) / 2 - 0.123 + 0.07])
     rad = (v - c).norm(dim=1)
