@@ -79,3 +79,36 @@ def test_export_obj(hip_lib, tmp_path):
     nv, nf = export_mesh(dec, {'planes_channel_last': pcl}, str(tmp_path / 'm.obj'), grid_size=32, thr=10.0)
     txt = open(tmp_path / 'm.obj').read().splitlines()
     assert nv > 0 and nf > 0 and sum(l.startswith('v ') for l in txt) == nv and sum(l.startswith('f ') for l in txt) == nf
+
+
+def test_mesh_from_grid_scale_rotation_colours_obj(hip_lib, tmp_path):
+    """nsr/train_util_diffusion.py:221-244 after the iso-surface: vertices (v / (G-1) * 2 - 1) * 0.45, colours = the decoder's rgb
+    re-queried at those points, rotation -90 degrees about x ((x, y, z) -> (x, z, -y)), .obj with per-vertex colours."""
+    import numpy as np
+    from ln3diff_amd.mesh import extract_isosurface, mesh_from_grid
+    from ln3diff_amd.synth import synth_input
+    from test_decode_gpu import build_decoder
+    dec = build_decoder(128, 2, 2).cuda()
+    dec.triplane_decoder.decoder.net[2].bias.data[0] += 10.0
+    pcl = synth_input('pcl', (1, 3, 128, 128, 32), 9, 4.0).cuda()
+    G = 24
+    grid = dec.triplane_decode_grid({'planes_channel_last': pcl}, G)
+    sigma = grid['sigma'][0].reshape(G, G, G)
+    v, f, col = mesh_from_grid(dec, {'planes_channel_last': pcl}, sigma, G, thr=10.0, path=str(tmp_path / 'm.obj'))
+    gv, gf = extract_isosurface(sigma.contiguous(), 10.0)
+    assert f.shape[0] > 50 and np.array_equal(f, gf.cpu().numpy())
+    world = (gv / (G - 1) * 2 - 1) * 0.45
+    w = world.cpu().numpy()
+    assert np.allclose(v, np.stack([w[:, 0], w[:, 2], -w[:, 1]], 1), atol=1e-6)
+    rgb = dec.forward_points(pcl, world[None])['rgb'][0]
+    assert np.array_equal(col, (rgb.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())
+    # the surface vertices sit on the iso-level of the decoder's density (trilinear interpolation of a smooth field: close)
+    sig_v = dec.forward_points(pcl, world[None])['sigma'][0, :, 0]
+    assert float((sig_v - 10.0).abs().median()) < 1.0
+    lines = open(tmp_path / 'm.obj').read().splitlines()
+    vl = [l.split() for l in lines if l.startswith('v ')]
+    fl = [l.split() for l in lines if l.startswith('f ')]
+    assert len(vl) == v.shape[0] and len(fl) == f.shape[0] and len(vl[0]) == 7
+    assert np.allclose(np.array(vl[5][1:4], dtype=np.float64), v[5], atol=1e-5)
+    assert np.allclose(np.array(vl[5][4:7], dtype=np.float64), col[5] / 255.0, atol=1e-3)
+    assert [int(i) - 1 for i in fl[3][1:4]] == list(f[3])
