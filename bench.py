@@ -260,11 +260,14 @@ def main():
     from ln3diff_amd import parallel
     from ln3diff_amd.pipeline import T23DPipeline, FlowMatchingEngine, render_video_given_triplane
     from ln3diff_amd.synth import orbit_cameras
-    rank, local_rank, world = parallel.setup_dist()
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:                       # before any rendezvous: a mismatched launch must fail, not hang
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line whose n_gpus is not "
+                         "what ran" % (args.gpus, env_world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    rank, local_rank, world = parallel.setup_dist()
+    assert world == args.gpus
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 

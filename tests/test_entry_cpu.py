@@ -54,3 +54,21 @@ def test_scripts_fail_loudly_without_gpu(script):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), "--logdir", "/tmp/ln3d_entry_test"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("argv,env,msg", [
+    (["--gpus", "2"], {}, "exposes"),                                  # self-spawn refuses when the box has fewer GPUs
+    (["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, "launcher started 2"),   # launcher / flag mismatch
+    (["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, "launcher started 4"),
+])
+def test_bench_refuses_wrong_gpu_counts(argv, env, msg):
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU box")
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode != 0 and msg in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])
+    assert '"metric"' not in r.stdout
