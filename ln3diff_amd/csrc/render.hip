@@ -530,19 +530,21 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
     float* zc_s = feat; float* zf_s = feat + 64; float* srt = feat + 128;   // srt: 128 x {z, sigma, r, g, b}
     zc_s[lane] = zc; zf_s[lane] = zf;
     wave_sync();
-    int rc = lane, rf = 0;
+    // Total order: by depth; equal depths: coarse before fine, then by lane.  The coarse depths are NOT assumed to be sorted by
+    // lane: on a ray that only grazes the box (t1 - t0 ~ 1e-5) rounding can swap two neighbours, and with a fine sample between
+    // them "rank = lane + ..." collided with it (garbage weights on ~1 ray per million at 512^2; the reference sorts for real).
+    int rc = 0, rf = 0;
 #pragma unroll 4
     for (int k = 0; k < NS; k += 4) {
       const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
       const float4 b = *reinterpret_cast<const float4*>(zc_s + k);
       rc += (a.x < zc) + (a.y < zc) + (a.z < zc) + (a.w < zc);
+      rc += (b.x < zc || (b.x == zc && k + 0 < lane)) + (b.y < zc || (b.y == zc && k + 1 < lane)) +
+            (b.z < zc || (b.z == zc && k + 2 < lane)) + (b.w < zc || (b.w == zc && k + 3 < lane));
       rf += (b.x <= zf) + (b.y <= zf) + (b.z <= zf) + (b.w <= zf);
       rf += (a.x < zf || (a.x == zf && k + 0 < lane)) + (a.y < zf || (a.y == zf && k + 1 < lane)) +
             (a.z < zf || (a.z == zf && k + 2 < lane)) + (a.w < zf || (a.w == zf && k + 3 < lane));
     }
-    // coarse depths are non-decreasing in lane but equal neighbours would collide: break ties by lane
-    // (z_i == z_j for i<j only if jitter/delta degenerate; ranks stay a permutation because rc counts
-    //  strictly-smaller fine + own index, rf counts coarse <= zf)
     srt[rc * 5 + 0] = zc; srt[rc * 5 + 1] = sigc; srt[rc * 5 + 2] = rgbc[0]; srt[rc * 5 + 3] = rgbc[1]; srt[rc * 5 + 4] = rgbc[2];
     srt[rf * 5 + 0] = zf; srt[rf * 5 + 1] = sigf; srt[rf * 5 + 2] = rgbf[0]; srt[rf * 5 + 3] = rgbf[1]; srt[rf * 5 + 4] = rgbf[2];
     wave_sync();

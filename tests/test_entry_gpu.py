@@ -36,3 +36,28 @@ def test_entry_points_run(hip_lib, tmp_path, objaverse, flags):
     lat2 = run(args2)
     assert torch.equal(lat2, lat)
     assert not np.array_equal(np.load(tmp_path / "b" / "frames_rank0.npy"), frames)
+
+
+def test_config3_xl2_text_cond_end_to_end(hip_lib, tmp_path):
+    """BASELINE configs[3] on one GPU's share at reduced steps: DiT-XL/2 text-conditioned EulerEDM + CFG -> decode -> views."""
+    args = create_argparser(True).parse_args(("--dit_model_arch DiT-XL/2 --trainer_name sgm_legacy --num_samples 2 --sample_steps 3 "
+                                              f"--image_size 64 --num_views 3 --logdir {tmp_path}").split())
+    lat = run(args)
+    assert lat.shape == (2, 12, 32, 32) and torch.isfinite(lat).all()
+    assert np.load(tmp_path / "frames_rank0.npy").shape == (2, 3, 3, 64, 64)
+
+
+def test_config4_i23d_512_24cams_mesh_end_to_end(hip_lib, tmp_path):
+    """BASELINE configs[4] on one GPU's share at reduced steps: DiT-PixArt-L/2 I23D flow matching, 24 cameras @ 512^2, marching-cubes
+    mesh export."""
+    args = create_argparser(True).parse_args(("--dit_model_arch DiT-PixArt-L/2 --i23d true --trainer_name flow_matching --num_samples 1 "
+                                              "--sample_steps 4 --unconditional_guidance_scale 4.0 --image_size 512 --num_views 24 "
+                                              f"--export_mesh true --mesh_grid 96 --mesh_thres 4.0 --logdir {tmp_path}").split())
+    lat = run(args)
+    assert lat.shape == (1, 12, 32, 32) and torch.isfinite(lat).all()
+    frames = np.load(tmp_path / "frames_rank0.npy")
+    depth = np.load(tmp_path / "depth_rank0.npy")
+    print('config4 frames', frames.shape, 'finite', bool(np.isfinite(frames).all()), 'absmax', float(np.nanmax(np.abs(frames))), 'latent std', float(lat.std()))
+    assert frames.shape == (1, 24, 3, 512, 512) and np.isfinite(frames).all() and np.abs(frames).max() <= 1.0 + 2e-3
+    assert depth.shape == (1, 24, 1, 512, 512) and np.isfinite(depth).all()
+    assert os.path.exists(tmp_path / "mesh_sample0.obj")

@@ -200,3 +200,26 @@ def test_views_per_call_matches_separate_calls(hip_lib):
     allv = tp(c=cams, planes_channel_last=pcl, plane_index=idx, jitter=j, u_fine=u)
     assert torch.equal(allv['image_raw'], one['image_raw'])
     assert float(allv['image_depth'].max()) >= float(one['image_depth'][:2].max())
+
+
+def test_grazing_rays_merge_is_a_permutation(hip_lib):
+    """Rays that only clip an edge of the sampling box (chord 1e-5 .. 1e-4): rounding un-sorts neighbouring coarse depths, and the
+    coarse / fine merge must still be a permutation (r2 regression: ~1 ray per million at 512^2 composited garbage - accumulated
+    weight -12 - because the merge assumed the coarse samples sorted by lane; the reference sorts for real)."""
+    res = 64
+    tp, planes, _, _, _ = _scene(res, 1)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    M = res * res
+    delta = 1e-5 + 9e-5 * torch.rand(M, device='cuda', generator=g)
+    z0 = (torch.rand(M, device='cuda', generator=g) - 0.5) * 0.8
+    s = 1.5
+    ro = torch.stack([0.45 + s + 0 * delta, -0.45 + delta + s, z0], -1)[None]                  # line x - y = 0.9 - delta
+    rd = torch.tensor([-1.0, -1.0, 0.0], device='cuda').div(2 ** 0.5).expand(1, M, 3).contiguous()
+    j = torch.rand(1, M, 64, device='cuda', generator=g)
+    u = torch.rand(M, 64, device='cuda', generator=g)
+    out = tp.renderer(planes.view(1, 3, 32, 128, 128), tp.decoder, ro.contiguous(), rd, tp.rendering_kwargs, jitter=j, u_fine=u)
+    w, f, d = out['weights_samples'], out['feature_samples'], out['depth_samples']
+    assert torch.isfinite(f).all() and torch.isfinite(w).all()
+    assert float(w.min()) >= -1e-6 and float(w.max()) <= 1 + 1e-5, (float(w.min()), float(w.max()))
+    assert float(f.abs().max()) <= 1.0 + 2e-3
+    assert float(d.min()) > 2.0 and float(d.max()) < 2.3                                        # the chord sits ~2.12 from the origins
