@@ -145,6 +145,34 @@ def test_attention(ops, B, H, Nq, Nk, Dh):
     assert e < 1e-2, e
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 256, 256), (1, 3, 512, 512), (5, 8, 768, 768), (19, 16, 768, 1024), (1, 2, 1280, 1280),
+                                       (2, 1, 2048, 2048), (1, 12, 3072, 3072), (3, 2, 200, 512), (2, 3, 768, 2304)])
+def test_attention_streaming_kernel_shapes(ops, B, H, Nq, Nk):
+    """attn_stream_kernel (Dh 64, Nk a multiple of 256): ring wrap at 1, 2, 3 .. 12 query / key blocks, head counts that do and do
+    not fill the chip, fewer queries than keys (the I23D appended-token layout), a spiked late key (deferred re-base), and the result
+    repeated bit for bit."""
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(Nq * 13 + Nk + B)
+    nqp = (Nq + 63) // 64 * 64
+    q = torch.zeros(B, H, nqp, 64)
+    q[:, :, :Nq] = torch.randn(B, H, Nq, 64, generator=g) * 1.5
+    k = torch.randn(B, H, Nk, 64, generator=g) * 1.5
+    v = torch.randn(B, H, Nk, 64, generator=g) + torch.arange(64) / 64
+    k[:, :, Nk - 37] = q[:, :, 5] * 4.0
+    k[:, :, 11] = q[:, :, Nq - 1] * 3.0
+    qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
+    vt = vb.transpose(-1, -2)[..., ops.vt_key_order(Nk, dev)].contiguous()
+    outs = []
+    for _ in range(2):
+        out = torch.empty(B, Nq, H * 64, device=dev, dtype=torch.bfloat16)
+        ops.attention(qb, kb, vt, out, B, H, Nq, nqp, Nk, Nk, 64)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = _attn_ref(qb[:, :, :Nq], kb, vb, 64 ** -0.5).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
+    e = rel_l2(outs[0].float(), ref)
+    assert e < 1e-2, e
+
+
 @pytest.mark.parametrize("D,kind", [(128, 0), (768, 0), (1024, 0), (1152, 0), (1024, 1)])
 def test_norm_modulate(ops, D, kind):
     dev = 'cuda'
