@@ -31,6 +31,7 @@ def test_reference_launcher_flags_parse():
     (("--i23d", "true", "--dit_model_arch", "DiT-L/2", "--trainer_name", "flow_matching"), "T23D architecture"),
     (("--i23d", "true", "--dit_model_arch", "DiT-PixArt-L/2"), "flow-matching"),         # I23D with the EDM engine
     (("--trainer_name", "no_such"), "known engines"),
+    (("--trainer_name", "flow_matching"), "needs an I23D denoiser"),                     # T23D arch with the flow-matching engine
     (("--create_controlnet", "true"), "ControlNet"),
     (("--arch_dit_decoder", "DiT2-Z/9"), "arch_dit_decoder"),
     (("--num_samples", "0"), ">= 1"),
