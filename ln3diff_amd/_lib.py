@@ -65,6 +65,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python __graft_entry__.py`).  ln3diff_amd has no CPU/eager fallback.")
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be in the process BEFORE this library is
+        # loaded, so that our NEEDED libamdhip64.so.7 resolves to the same runtime; loaded the other way round (build() then
+        # smoke() in one process) /opt/rocm's copy comes in first, torch then loads its own, and launches on torch's streams
+        # fail with "HIP kernel launch failed".
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.ln3d_strerror.restype = C.c_char_p
         for s in SYMBOLS:

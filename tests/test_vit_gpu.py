@@ -59,8 +59,15 @@ def test_dinov2_tower_vs_golden(hip_lib, name, B):
     assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
 
 
-def test_image_embedder_rejects_unresized_input(hip_lib):
-    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder
+def test_image_embedder_resizes_other_input_sizes(hip_lib):
+    """preprocess (sgm/modules/encoders/modules.py:633-645): inputs that are not at the tower's size go through the kornia-style
+    bicubic / align_corners / antialias resize (restated, unpinned) instead of being rejected; inputs at size bypass it."""
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder, resize_bicubic_antialias
     m = FrozenDinov2ImageEmbedder(width=128, layers=1, heads=2, image_size=56)
-    with pytest.raises(RuntimeError):
-        m(torch.zeros(1, 3, 64, 64, device='cuda'))
+    x = torch.rand(1, 3, 64, 64, device='cuda') * 2 - 1
+    a = m(x)
+    b = m(resize_bicubic_antialias(x, (56, 56)))
+    ta, tb = (a if torch.is_tensor(a) else a[0]), (b if torch.is_tensor(b) else b[0])
+    assert torch.equal(ta, tb)
+    c = torch.ones(2, 3, 300, 260, device='cuda')
+    assert float((resize_bicubic_antialias(c, (224, 224)) - 1).abs().max()) < 1e-5
