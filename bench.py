@@ -66,11 +66,11 @@ def roofline_probe(dev, n_net, D, iters=20, tokens=768):
     peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
     ach = flops / (ms * 1e-3) / 1e12
     # traffic: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch of this kernel at this shape, from the separate
-    # rocprofv3 --pmc passes committed in profiles/r1_e_pmc.md (bench.py cannot run the profiler on itself)
-    traffic = 277.4e6 if (M, N, K) == (12288, 4096, 1024) else None
+    # rocprofv3 --pmc passes committed in profiles/r2_e_pmc.md (bench.py cannot run the profiler on itself)
+    traffic = 277.5e6 if (M, N, K) == (12288, 4096, 1024) else None
     return {"kernel": "gemm_bf16_ring64_kernel<GELU_ERF, 256x256> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
             "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-            "traffic_source": "profiles/r1_e_pmc.md (bytes per launch at the L2 fabric boundary)", "avg_us": round(ms * 1e3, 2),
+            "traffic_source": "profiles/r2_e_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate --pmc passes)", "avg_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops}
 
 
@@ -95,8 +95,8 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     stream = (N % 256 == 0 and Dh == 64 and not os.environ.get('LN3D_ATTN_V'))
     return {"kernel": ("attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<64,4>") +
                       " - DiT self-attention, %d queries x %d keys" % (Nq, N), "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
-            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 150e6 if N == 768 else None,
-            "traffic_source": "profiles/r2_attn_pmc.md (K/V re-reads miss the 4 MB XCD L2; instruction-issue bound, see there)"}
+            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 230.9e6 if (N == 768 and Nq == 768 and n_net == 16 and H == 16) else None,
+            "traffic_source": "profiles/r2_e_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE; K / V^T re-reads miss the 4 MB XCD L2: 11.8 % hits), profiles/r2_attn_pmc.md (instruction-issue bound)"}
 
 
 def render_probe(dev, dec, res=256, V=4, iters=5):
@@ -127,7 +127,8 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
             "definition": "algorithmic gather bytes (1536 B/sample point) / time; the texels are L2-resident so this is an L2-gather "
                           "rate, not HBM traffic - judge the kernel on ms_per_view vs target_ms_per_view",
             "ms_per_view": round(ms / V, 3), "target_ms_per_view": 2.7, "mlp_issued_bf16_tflops": round(mlp_tflops, 1),
-            "traffic": None, "traffic_source": "profiles/r2_render_pmc.md"}
+            "traffic": 0.39e9 if (V, res) == (4, 256) else None,
+            "traffic_source": "profiles/r2_render_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE of one 4-view launch: 0.12 TB/s - not an HBM-bound kernel)"}
 
 
 def cpu_baseline(arch, steps_total, views, res, B):
