@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops, _cache
-from .._lib import RENDER_SCRATCH_FLOATS
+from .._lib import RENDER_SCRATCH_FLOATS, RENDER_MAX_CALLS
 from .volumetric_rendering.renderer import ImportanceRenderer, check_rendering_options, draw_render_noise  # noqa: F401
 
 
@@ -115,11 +115,20 @@ class Triplane(nn.Module):
         fs = torch.empty(V, M, S, device=dev) if details else None
         cc = torch.empty(V, M, S, 3, device=dev) if details else None
         fc = torch.empty(V, M, S, 3, device=dev) if details else None
-        ops.render_triplane(planes_channel_last, H, W, plane_index.to(dev, torch.int32).contiguous(),
-                            c.to(torch.float32).contiguous(), res, self._decoder_dev(dev), jitter, u_fine, rgb, depth,
-                            wsum, lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
-                            bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=cs,
-                            fine_depths=fd, fine_sigma=fs, coarse_coords=cc, fine_coords=fc, views_per_call=views_per_call)
+        pidx = plane_index.to(dev, torch.int32).contiguous()
+        cam = c.to(torch.float32).contiguous()
+        # one launch handles at most RENDER_MAX_CALLS reference calls (range records in the scratch): more are rendered in chunks of
+        # whole calls, which is exact because calls are independent
+        vpc = V if (views_per_call <= 0 or views_per_call > V) else views_per_call
+        chunk = V if (V + vpc - 1) // vpc <= RENDER_MAX_CALLS else RENDER_MAX_CALLS * vpc
+        sl = lambda t, a, b, per=1: None if t is None else t[a * per:b * per]
+        for a in range(0, V, chunk):
+            b = min(V, a + chunk)
+            ops.render_triplane(planes_channel_last, H, W, pidx[a:b], cam[a:b], res, self._decoder_dev(dev), jitter[a:b], u_fine[a * M:b * M],
+                                rgb[a:b], depth[a:b], wsum[a:b], lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
+                                bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=sl(cs, a, b),
+                                fine_depths=sl(fd, a, b), fine_sigma=sl(fs, a, b), coarse_coords=sl(cc, a, b), fine_coords=sl(fc, a, b),
+                                views_per_call=views_per_call if chunk == V else vpc)
         ret = {'feature_image': rgb, 'image_raw': rgb, 'image_depth': depth, 'weights_samples': wsum,
                'image_mask': wsum * (1 + 2 * 0.001) - 0.001,
                'shape_synthesized': {'image_depth': depth, 'depth': depth.reshape(V, M, 1)}}

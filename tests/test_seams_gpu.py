@@ -223,3 +223,24 @@ def test_grazing_rays_merge_is_a_permutation(hip_lib):
     assert float(w.min()) >= -1e-6 and float(w.max()) <= 1 + 1e-5, (float(w.min()), float(w.max()))
     assert float(f.abs().max()) <= 1.0 + 2e-3
     assert float(d.min()) > 2.0 and float(d.max()) < 2.3                                        # the chord sits ~2.12 from the origins
+
+
+def test_more_reference_calls_than_one_launch_holds(hip_lib):
+    """views_per_call=1 with more views than the scratch has range records (1749): rendered in chunks of whole calls, identical to
+    rendering the halves separately."""
+    from ln3diff_amd._lib import RENDER_MAX_CALLS
+    from ln3diff_amd.synth import orbit_cameras
+    res, V = 8, RENDER_MAX_CALLS + 51
+    tp, planes, _, _, _ = _scene(res, 1)
+    cams = orbit_cameras(24).cuda().repeat((V + 23) // 24, 1)[:V].contiguous()
+    g = torch.Generator(device='cuda').manual_seed(4)
+    j = torch.rand(V, res * res, 64, device='cuda', generator=g)
+    u = torch.rand(V * res * res, 64, device='cuda', generator=g)
+    pcl = tp.to_channel_last(planes)
+    idx = torch.zeros(V, dtype=torch.int32, device='cuda')
+    whole = tp(c=cams, planes_channel_last=pcl, plane_index=idx, jitter=j, u_fine=u, views_per_call=1)
+    h = 1000
+    a = tp(c=cams[:h], planes_channel_last=pcl, plane_index=idx[:h], jitter=j[:h], u_fine=u[:h * res * res], views_per_call=1)
+    b = tp(c=cams[h:], planes_channel_last=pcl, plane_index=idx[h:], jitter=j[h:], u_fine=u[h * res * res:], views_per_call=1)
+    for k in ('image_raw', 'image_depth', 'weights_samples'):
+        assert torch.equal(whole[k], torch.cat([a[k], b[k]])), k
