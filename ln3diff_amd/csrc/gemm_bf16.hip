@@ -362,7 +362,12 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
           }
           uint4 o;
           o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w); o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
-          if (tb + row < p.M && f8 < p.N) *reinterpret_cast<uint4*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + f8) = o;
+          if (tb + row < p.M && f8 < p.N) {
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t ov = {o.x, o.y, o.z, o.w};
+            u32x4_t* dstp = reinterpret_cast<u32x4_t*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + f8);
+            __builtin_nontemporal_store(ov, dstp);   // streaming store: the activations are read once, by the next kernel (fc1 -3 us, within box noise)
+          }
         }
       } else {
 #pragma unroll
