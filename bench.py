@@ -335,6 +335,11 @@ def main():
                   "per GPU, VAE decode %s + conv decoder, %d views @ %d^2 (64+64 samples/ray)"
                   % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res))
             metric = "3D samples/sec (250-step DiT-L/2 + 256^2 triplane render)"
+        ref_cfg = dict(arch="DiT-PixArt-L/2", sample_steps=50, batch=32, views=24, res=256) if i23d else \
+            dict(arch="DiT-L/2", sample_steps=250, batch=8, views=40, res=256)
+        dev_from = {k: getattr(args, k) for k, v in ref_cfg.items() if getattr(args, k) != v}
+        if dev_from:           # a reduced / altered run must not pass for the headline configuration
+            metric += " [NOT the baseline configuration: %s]" % ", ".join("%s=%s" % kv for kv in sorted(dev_from.items()))
         rec = {
             "metric": metric, "value": round(Bt * args.steps / dt, 5),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
