@@ -244,3 +244,54 @@ def test_more_reference_calls_than_one_launch_holds(hip_lib):
     b = tp(c=cams[h:], planes_channel_last=pcl, plane_index=idx[h:], jitter=j[h:], u_fine=u[h * res * res:], views_per_call=1)
     for k in ('image_raw', 'image_depth', 'weights_samples'):
         assert torch.equal(whole[k], torch.cat([a[k], b[k]])), k
+
+
+def test_explicit_ray_fuzz_vs_oracle(hip_lib):
+    """ImportanceRenderer.forward on ray bundles the cameras never produce, against the CPU oracle on the same rays and noise:
+    camera-like rays, rays that clip an edge of the box, rays that miss it (the invalid-ray fix-up), origins inside the box,
+    axis-parallel directions (zero components in the slab test)."""
+    from oracle import render as orender
+    from test_render_gpu import _decoder_sd
+    res = 48
+    M = res * res
+    tp, planes, _, _, _ = _scene(res, 1)
+    g = torch.Generator().manual_seed(23)
+    n = M // 6
+    def unit(v):
+        return v / v.norm(dim=-1, keepdim=True)
+    # a) orbit-like: origins on a sphere of radius 1.8, aimed at points inside the box
+    o_a = unit(torch.randn(n, 3, generator=g)) * 1.8
+    d_a = unit((torch.rand(n, 3, generator=g) - 0.5) * 0.8 - o_a)
+    # b) edge-clipping: line x - y = 0.9 - delta in a z = const plane, chord 1e-4 .. 1e-2
+    delta = 1e-4 + 1e-2 * torch.rand(n, generator=g)
+    o_b = torch.stack([0.45 + 1.5 + 0 * delta, -0.45 + delta + 1.5, (torch.rand(n, generator=g) - 0.5) * 0.8], -1)
+    d_b = torch.tensor([-1.0, -1.0, 0.0]).div(2 ** 0.5).expand(n, 3)
+    # c) misses: aimed well outside the box
+    o_c = unit(torch.randn(n, 3, generator=g)) * 1.8
+    d_c = unit(unit(torch.randn(n, 3, generator=g)) * 1.5 - o_c)
+    # d) origins inside the box
+    o_d = (torch.rand(n, 3, generator=g) - 0.5) * 0.6
+    d_d = unit(torch.randn(n, 3, generator=g))
+    # e) axis-parallel
+    o_e = torch.stack([torch.full((n,), 1.7), (torch.rand(n, generator=g) - 0.5) * 0.8, (torch.rand(n, generator=g) - 0.5) * 0.8], -1)
+    d_e = torch.tensor([-1.0, 0.0, 0.0]).expand(n, 3)
+    # f) the rest: more orbit-like rays
+    r = M - 5 * n
+    o_f = unit(torch.randn(r, 3, generator=g)) * 1.6
+    d_f = unit(-o_f + (torch.rand(r, 3, generator=g) - 0.5) * 0.3)
+    ro = torch.cat([o_a, o_b, o_c, o_d, o_e, o_f])[None].contiguous()
+    rd = torch.cat([d_a, d_b, d_c, d_d, d_e, d_f])[None].contiguous()
+    j = torch.rand(1, M, 64, generator=g)
+    u = torch.rand(M, 64, generator=g)
+    out = tp.renderer(planes.view(1, 3, 32, 128, 128), tp.decoder, ro.cuda(), rd.cuda(), tp.rendering_kwargs, jitter=j.cuda(), u_fine=u.cuda())
+    ref = orender.render(planes.cpu().view(1, 3, 32, 128, 128), _decoder_sd(4.0), ro, rd, j.unsqueeze(-1), u)
+    names = ['orbit', 'edge', 'miss', 'inside', 'axis', 'orbit2']
+    bounds = [0, n, 2 * n, 3 * n, 4 * n, 5 * n, M]
+    for key, rk in (('feature_samples', 'rgb'), ('weights_samples', 'weights_sum'), ('depth_samples', 'depth')):
+        a, b = out[key][0].cpu(), ref[rk][0]
+        assert torch.isfinite(a).all(), key
+        for i, nm in enumerate(names):
+            sl = slice(bounds[i], bounds[i + 1])
+            e = rel_l2(a[sl], b[sl])
+            print(key, nm, e, float((a[sl] - b[sl]).abs().max()))
+            assert e < 3e-3, (key, nm, e)
