@@ -42,9 +42,9 @@ def test_full_edm_ditl2_250_vs_reference_golden(hip_lib):
     errs = {k: rel_l2(t.cpu(), g[k]) for k, t in (('first', tr[0]), ('s50', tr[50]), ('s125', tr[125]), ('s200', tr[200]), ('final', y))}
     print('full EDM-250 DiT-L/2:', errs)
     assert torch.isfinite(y).all()
-    assert errs['first'] < 2e-3, errs            # one bf16 network evaluation on a sigma~157 state
-    assert errs['s50'] < 2e-2 and errs['s125'] < 3e-2, errs
-    assert errs['final'] < 5e-2, errs            # same bound as the tiny-model 250-step loop
+    # measured 1.1e-4 / 1.6e-3 / 1.7e-3 / 1.7e-3 / 1.7e-3: the error saturates (the sampler contracts), it does not compound
+    assert errs['first'] < 1e-3, errs            # one bf16 network evaluation on a sigma~157 state
+    assert max(errs['s50'], errs['s125'], errs['s200'], errs['final']) < 1e-2, errs
 
 
 def test_full_flow_pixartl2_euler50_vs_reference_golden(hip_lib):
@@ -62,7 +62,7 @@ def test_full_flow_pixartl2_euler50_vs_reference_golden(hip_lib):
     y = eng.sample(cond, None, batch_size=1, cfg_scale=4.0, num_steps=50, zs=z)
     e = rel_l2(y.cpu(), g['final'])
     print('full flow euler-50 DiT-PixArt-L/2 final', e)
-    assert y.shape == (1, 12, 32, 32) and e < 3e-2, e
+    assert y.shape == (1, 12, 32, 32) and e < 1e-2, e                  # measured 2.1e-3
 
 
 @pytest.mark.parametrize("res", [128, 256])
@@ -118,7 +118,7 @@ def test_chain_latent_to_views_vs_reference_golden(hip_lib):
     latent = pipe.sample(c2, None, batch_size=2, seed=int(g['z_seed']))
     e_lat = rel_l2(latent.cpu(), g['latent'])
     print('chain latent', e_lat)
-    assert e_lat < 2e-2, e_lat
+    assert e_lat < 5e-3, e_lat                                       # measured 3.3e-4
     # part 2: golden latent[0] -> AE behaviours.  Render noise: the reference renders ONE camera per call from a stream seeded 0
     cams = torch.from_numpy(g['cams']).cuda()
     gen = torch.Generator().manual_seed(int(g['jitter_seed']))
@@ -133,14 +133,14 @@ def test_chain_latent_to_views_vs_reference_golden(hip_lib):
     for key in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
         e = rel_l2(out[key][0].cpu(), g[key])
         print('chain', key, e)
-        assert e < 3e-2, (key, e)                                   # bf16 decoder (planes 3e-2) in front of the fp32 renderer
+        assert e < 5e-3, (key, e)                                   # measured 5e-5 .. 2.2e-4 (planes 1.6e-2: the renderer averages)
     d = {'latent_normalized_2Ddiffusion': planes}
     d.update(ae(latent=d, behaviour='decode_after_vae_no_render'))
     grid = ae(latent=d, grid_size=8, behaviour='triplane_decode_grid')
     assert grid['sigma'].shape == (1, 8, 8, 8, 1) and grid['rgb'].shape == (1, 8, 8, 8, 3)
     e_s, e_c = rel_l2(grid['sigma'].cpu(), g['grid_sigma']), rel_l2(grid['rgb'].cpu(), g['grid_rgb'])
     print('chain grid sigma', e_s, 'rgb', e_c)
-    assert e_s < 3e-2 and e_c < 3e-2, (e_s, e_c)
+    assert e_s < 5e-3 and e_c < 5e-3, (e_s, e_c)                    # measured 6e-4
     # one-call and two-call AE routes agree bit for bit
     one = ae(latent={'latent_normalized_2Ddiffusion': planes}, c=cams, behaviour='decode_after_vae', jitter=torch.cat(js), u_fine=torch.cat(us))
     assert one['image_raw'].shape[0] == 2
@@ -171,7 +171,7 @@ def test_ddpm_tiny_250_vs_reference_golden(hip_lib):
     y = diff.p_sample_loop(m, (2, 12, 32, 32), cond=ctx, noise=z, clip_denoised=False, mixing_normal=False, step_noise=lambda k: noises[k])
     e = rel_l2(y.cpu(), g['final'])
     print('ddpm 250 final', e)
-    assert e < 5e-2, e
+    assert e < 5e-3, e                                              # measured 5.3e-5
 
 
 def test_operand_rounding_explains_the_gap(hip_lib):
