@@ -62,7 +62,7 @@ def test_flow_matching_ode_vs_reference_golden(hip_lib, method, steps):
     y = fn(torch.cat([z, z]), m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)[-1].chunk(2)[0].cpu()
     e = rel_l2(y, g['final'])
     print('flow', method, steps, e)
-    assert e < 5e-2, e
+    assert e < 1e-2, e          # measured 1.7e-3 .. 1.9e-3
 
 
 @pytest.mark.parametrize("method,steps,form,last", [('Euler', 25, 'sigma', 'Mean'), ('Heun', 8, 'linear', 'Euler'),
@@ -85,7 +85,7 @@ def test_flow_matching_sde_vs_reference_golden(hip_lib, method, steps, form, las
     assert len(xs) == steps
     e = rel_l2(xs[-1].chunk(2)[0].cpu(), g['final'])
     print('sde', method, steps, form, last, e)
-    assert e < 5e-2, e
+    assert e < 1e-2, e          # measured 1.7e-3 .. 1.9e-3
     with pytest.raises(TypeError):
         Sampler(create_transport()).sample_sde(diffusion_form='constant', num_steps=3)(z, m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)
 

@@ -1,6 +1,7 @@
 """GPU parity of the device-resident sampler loops against the reference goldens (final latents).
 The loops are chaotic amplifiers of rounding error, so the tolerance is on the FINAL latent relative to its norm:
-bf16 network inside an fp32 sampler state: rel-L2 <= 5e-2 after 10..50 steps (per-step network error ~1e-3)."""
+bf16 network inside an fp32 sampler state: rel-L2 <= 1e-2 after 10..250 steps (measured 1.6e-4 .. 3.2e-4: the samplers
+contract, the per-step network error ~1e-3 does not compound)."""
 import pytest
 import torch
 
@@ -36,7 +37,7 @@ def test_edm_euler_cfg_vs_reference_golden(hip_lib, steps):
     y = sampler(den, m, z, cond, uc, trace=tr)
     e0, em, e1 = rel_l2(tr[0].cpu(), g['first']), rel_l2(tr[steps // 2].cpu(), g['mid']), rel_l2(y.cpu(), g['final'])
     print('edm', steps, 'first', e0, 'mid', em, 'final', e1)
-    assert e0 < 2e-3 and e1 < 5e-2, (e0, em, e1)
+    assert e0 < 2e-3 and e1 < 1e-2, (e0, em, e1)
 
 
 def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
@@ -62,7 +63,7 @@ def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
                            step_noise=lambda k: noises[k], trace=tr)
     e0, e24, e = rel_l2(tr[0].cpu(), g['step0']), rel_l2(tr[24].cpu(), g['step24']), rel_l2(y.cpu(), g['final'])
     print('config1 step0', e0, 'step24', e24, 'final', e)
-    assert e0 < 2e-3 and e < 5e-2, (e0, e24, e)
+    assert e0 < 2e-3 and e < 1e-2, (e0, e24, e)
 
 
 @pytest.mark.parametrize("spec", ['ddim50', 'ddim25'])
@@ -81,4 +82,4 @@ def test_ddim_cfg_vs_reference_golden(hip_lib, spec):
                               unconditional_guidance_scale=float(g['scale']), step_noise=lambda k: noises[k])
     e = rel_l2(y.cpu(), g['final'])
     print('ddim', spec, e)
-    assert e < 5e-2, e
+    assert e < 1e-2, e
