@@ -72,6 +72,12 @@ typedef struct {
   float ctx_scale;         /* CROSS_ATTN: softmax scale (head_dim^-0.5) */
   int head_dim_pad;   /* HEADS: destination head size (>= head_dim; 0 = head_dim).  DiT-XL/2 (head_dim 72) writes into
                          128-wide zero-initialised heads so that ln3d_attention_bf16 (Dh 64/128) serves it */
+  /* HEADS: optional qk_norm fused into the epilogue - per-head RMSNorm weights [64] for output 0 (q) / output 1 (k), applied to
+   * the fp32 accumulators (+ bias) before the single rounding to bf16: x * rsqrt(mean_64(x^2) + head_norm_eps) * w
+   * (vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294).  Needs head_dim == 64, tokens % 32 == 0,
+   * M % tokens == 0, M >= 1536, N >= 128 (the head-aligned tiles); otherwise LN3D_ERR_UNSUPPORTED - run ln3d_rmsnorm_heads_bf16
+   * after the GEMM instead.  NULL = no normalisation. */
+  const float* head_norm0; const float* head_norm1; float head_norm_eps;
 } ln3d_gemm_args;
 
 int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);

@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("out0", vp), ("out1", vp), ("out2", vp), ("ldo", i64),
                 ("gate", vp), ("gate_rows", i32), ("gate_ld", i64),
                 ("tokens", i32), ("tok_pad", i32), ("heads", i32), ("head_dim", i32),
-                ("transpose_mask", i32), ("ctx_keys", i32), ("ctx_pad", i32), ("ctx_scale", f32), ("head_dim_pad", i32)]
+                ("transpose_mask", i32), ("ctx_keys", i32), ("ctx_pad", i32), ("ctx_scale", f32), ("head_dim_pad", i32),
+                ("head_norm0", vp), ("head_norm1", vp), ("head_norm_eps", f32)]
 
 
 class AttnArgs(C.Structure):
@@ -83,7 +84,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 5
+    assert L.ln3d_abi_version() == 6
     return True
 
 

@@ -697,4 +697,4 @@ extern "C" const char* ln3d_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int ln3d_abi_version(void) { return 5; }
+extern "C" int ln3d_abi_version(void) { return 6; }

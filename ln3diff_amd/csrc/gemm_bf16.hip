@@ -37,6 +37,7 @@ struct GemmP {
   const float* gate; int gate_rows; int64_t gate_ld;
   int tokens, tok_pad, heads, head_dim, transpose_mask, head_dim_pad;
   int ctx_keys, ctx_pad; float ctx_scale_log2;
+  const float* hn0; const float* hn1; float hn_eps;   // HEADS: fused qk_norm weights (outputs 0 / 1) or NULL
   int abl;   // bench-only ablation bits of the ring kernel (LN3D_GEMM_ABL): 1 = skip the epilogue, 2 = 2 K-stages only, 4 = no DMA in steady state
 };
 
@@ -730,6 +731,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
           const int r8 = lane >> 3, c8 = lane & 7;
           float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
           if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8); b1 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8 + 4); }
+          // fused qk_norm: the 8 lanes c8 = 0..7 of a row hold the 64 features of one (token, head)
+          const float* nw = which == 0 ? p.hn0 : (which == 1 ? p.hn1 : nullptr);
+          float4 n0 = make_float4(1.f, 1.f, 1.f, 1.f), n1 = n0;
+          if (nw) { n0 = *reinterpret_cast<const float4*>(nw + 8 * c8); n1 = *reinterpret_cast<const float4*>(nw + 8 * c8 + 4); }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int tb = __builtin_amdgcn_readfirstlane(t0 + wt * 32 * NJ + j * 32);
@@ -746,11 +751,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               const int row = 8 * it + r8;
-              const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
-              const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+              float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+              float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+              v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w; v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+              if (nw) {                                            // wave-uniform
+                float ss = (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+                ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+                ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+                ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xf, 0xf, false));   // row_half_mirror
+                const float rs = rsqrtf(ss * (1.0f / 64.0f) + p.hn_eps);
+                v0.x *= rs * n0.x; v0.y *= rs * n0.y; v0.z *= rs * n0.z; v0.w *= rs * n0.w;
+                v1.x *= rs * n1.x; v1.y *= rs * n1.y; v1.z *= rs * n1.z; v1.w *= rs * n1.w;
+              }
               uint4 o;
-              o.x = pack2bf(v0.x + b0.x, v0.y + b0.y); o.y = pack2bf(v0.z + b0.z, v0.w + b0.w);
-              o.z = pack2bf(v1.x + b1.x, v1.y + b1.y); o.w = pack2bf(v1.z + b1.z, v1.w + b1.w);
+              o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w);
+              o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
               *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * p.tok_pad + t + row) * 64 + 8 * c8) = o;
             }
           }
@@ -843,7 +858,7 @@ static int num_cus() {
 // throughput of the tile shape (measured at K = 1024 on MI355X: 256x256 1.00, 256x192 0.95, 128x384 0.945 - the L2 -> LDS
 // fill is the limiter, so throughput follows the tile's flop/byte).  DiT-L/2 at 12288 tokens: N = 4096 -> 256x256 (3 full
 // rounds), N = 3072 -> 384x192 with 12 waves (2 full rounds), N = 1024 -> 256x192 (1 full round).
-static int pick_cfg(int M, int N) {
+static int pick_cfg(int M, int N, bool head_aligned = false) {
   const char* force = getenv("LN3D_GEMM_TILE");
   if (force && force[0] == 's') return 0;
   if (force && force[0] == 'x') return atoi(force + 1);
@@ -853,6 +868,9 @@ static int pick_cfg(int M, int N) {
   const int cus = num_cus();
   int best = 8; float best_cost = 1e30f;
   for (int i = 0; i < 4; ++i) {
+    // head split with 64-wide heads: only the configurations whose wave row is ONE head (64 features, NI = 2) have the
+    // head-contiguous staged epilogue; at the I23D shapes (65536 x 3072) 256x256 costs 550 us against 500 (384x192)
+    if (head_aligned && C[i].cfg == 7) continue;
     const int64_t tiles = (int64_t)((N + C[i].bf - 1) / C[i].bf) * ((M + C[i].bt - 1) / C[i].bt);
     const float cost = (float)((tiles + cus - 1) / cus) * (float)(C[i].bf * C[i].bt) / C[i].speed;
     if (cost < best_cost) { best_cost = cost; best = C[i].cfg; }
@@ -874,9 +892,10 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.transpose_mask = a->transpose_mask;
   p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
   p.ctx_keys = a->ctx_keys; p.ctx_pad = a->ctx_pad; p.ctx_scale_log2 = a->ctx_scale * 1.4426950408889634f;
+  p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
   { const char* e = getenv("LN3D_GEMM_ABL"); p.abl = e ? atoi(e) : 0; }
   hipStream_t s = (hipStream_t)stream;
-  const int cfg = pick_cfg(a->M, a->N);
+  const int cfg = pick_cfg(a->M, a->N, a->epilogue == LN3D_EPI_HEADS && a->head_dim == 64 && a->head_dim_pad <= 64);
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);
     case LN3D_EPI_BF16: return run_cfg<LN3D_EPI_BF16>(p, s, cfg);
@@ -897,6 +916,10 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
     case LN3D_EPI_HEADS:
       if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens)
         return LN3D_ERR_BAD_ARG;
+      if ((a->head_norm0 || a->head_norm1) &&
+          !((cfg == 8 || cfg == 9 || cfg == 12) && a->head_dim == 64 && p.head_dim_pad == 64 && (a->tokens & 31) == 0 &&
+            (a->M % a->tokens) == 0 && (a->N % 64) == 0))
+        return LN3D_ERR_UNSUPPORTED;                  // only the head-aligned staged epilogue normalises
       return run_cfg<LN3D_EPI_HEADS>(p, s, cfg);
     default: return LN3D_ERR_UNSUPPORTED;
   }

@@ -201,14 +201,18 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
         ld = 6 * D
         probe = getattr(self, '_fc1_probe', None)
+        fuse_cq = ops.heads_norm_fusable(M, H * 64, N, 64)
         for i, q in enumerate(P['blocks']):
             mi = mod[i]
             ops.norm_modulate(xt, ha, M, D, kind=1, eps=1e-5, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
                               mod_ld=ld, rows_in=N, rows_out=NA)
             ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
             ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld)
-            ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
-            ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
+            if fuse_cq:        # qk_norm of the cross-attention query inside the projection's epilogue
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64, head_norm0=q['cqn'])
+            else:
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
+                ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
             ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
             ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
             ops.norm_modulate(xt, hb, M, D, kind=1, eps=1e-5, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],

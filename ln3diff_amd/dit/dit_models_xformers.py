@@ -227,9 +227,10 @@ def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=No
     k = ws.get(tag + 'k', (B, H, npad, Dp), torch.bfloat16, zero=True)
     vt = ws.get(tag + 'vt', (B, H, Dp, npad), torch.bfloat16, zero=True)
     o = ws.get(tag + 'o', (B * nq, H * Dp), torch.bfloat16)
+    fused = qn is not None and ops.heads_norm_fusable(B * N, qkv_w.shape[0], N, Dh, Dp)
     ops.gemm(h_bf16, qkv_w, qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
-             transpose_mask=0b100, head_dim_pad=Dp)
-    if qn is not None:
+             transpose_mask=0b100, head_dim_pad=Dp, head_norm0=qn if fused else None, head_norm1=kn if fused else None)
+    if qn is not None and not fused:
         ops.rmsnorm_heads(q, qn, B * H * npad, Dp, true_dim=Dh)      # qn / kn: [Dp] (zero beyond Dh when padded)
         ops.rmsnorm_heads(k, kn, B * H * npad, Dp, true_dim=Dh)
     ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dp, scale=Dh ** -0.5)

@@ -115,6 +115,52 @@ def test_gemm_heads_split(ops):
     assert float(q[:, :, T:].abs().max()) == 0 and float(vt_nat[:, :, :, T:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,T,H,K", [(4, 768, 16, 1024), (2, 1024, 4, 256), (3, 800, 2, 128)])
+def test_gemm_heads_split_with_fused_qk_norm(ops, B, T, H, K):
+    """HEADS epilogue with head_norm0 / head_norm1: q, k = RMSNorm_64(x W^T + b) * w per (token, head), one rounding to bf16;
+    V^T untouched.  Shapes take the 384x192, 256x192 and 128x384 head-aligned tiles; small / unaligned problems must refuse."""
+    dev = 'cuda'
+    Dh = 64
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B * T, K, generator=g).to(dev)
+    w = (torch.randn(3 * H * Dh, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(3 * H * Dh, generator=g).to(dev)
+    nq = (1 + 0.3 * torch.randn(Dh, generator=g)).to(dev)
+    nk = (1 + 0.3 * torch.randn(Dh, generator=g)).to(dev)
+    xb, wb = _bf(x), _bf(w)
+    import os
+    forced = os.environ.get('LN3D_GEMM_TILE')
+    assert ops.heads_norm_fusable(B * T, 3 * H * Dh, T, Dh) == (forced is None)
+    if forced not in (None, 'x8', 'x9', 'x12'):          # tiles without the head-aligned epilogue refuse
+        with pytest.raises(RuntimeError):
+            ops.gemm(xb, wb, b, ops.EPI_HEADS, torch.zeros(B, H, T, Dh, device=dev, dtype=torch.bfloat16), None, None, M=B * T, tokens=T,
+                     tok_pad=T, heads=H, head_dim=Dh, head_norm0=nq)
+        return
+    ref = (xb.float() @ wb.float().t() + b).reshape(B, T, 3, H, Dh)
+    rms = lambda t, wt: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * wt
+    q = torch.zeros(B, H, T, Dh, device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, Dh, T, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_HEADS, q, k, vt, M=B * T, tokens=T, tok_pad=T, heads=H, head_dim=Dh, transpose_mask=0b100,
+             head_norm0=nq, head_norm1=nk, head_norm_eps=1e-5)
+    assert rel_l2(q.float(), rms(ref[:, :, 0], nq).permute(0, 2, 1, 3)) < 4e-3
+    assert rel_l2(k.float(), rms(ref[:, :, 1], nk).permute(0, 2, 1, 3)) < 4e-3
+    vt_nat = torch.zeros_like(vt)
+    vt_nat[..., ops.vt_key_order(T, dev)] = vt
+    assert rel_l2(vt_nat.float(), ref[:, :, 2].permute(0, 2, 3, 1)) < 4e-3
+    # agrees with the two-kernel route (GEMM, then ln3d_rmsnorm_heads_bf16 on the rounded q) to bf16 rounding
+    q2 = torch.zeros_like(q)
+    k2 = torch.zeros_like(q)
+    ops.gemm(xb, wb, b, ops.EPI_HEADS, q2, k2, vt, M=B * T, tokens=T, tok_pad=T, heads=H, head_dim=Dh, transpose_mask=0b100)
+    ops.rmsnorm_heads(q2, nq, B * H * T, Dh)
+    assert rel_l2(q.float(), q2.float()) < 6e-3
+    # the small-problem kernel has no such epilogue: refused, not silently un-normalised
+    if forced is None:
+      with pytest.raises(RuntimeError):
+        ops.gemm(xb[:512], wb, b, ops.EPI_HEADS, q, k, vt, M=512, tokens=256, tok_pad=T, heads=H, head_dim=Dh, transpose_mask=0b100,
+                 head_norm0=nq)
+
+
 def _attn_ref(q, k, v, scale):
     s = (q.float() @ k.float().transpose(-1, -2)) * scale
     return torch.softmax(s, -1) @ v.float()
