@@ -12,8 +12,13 @@ def bump(*_a, **_k):
     EPOCH[0] += 1
 
 
-def stamp(cache):
+def stamp(cache, owner=None):
+    """Mark a freshly built cache with the current epoch.  `owner` (the module the cache belongs to) gets the load hook on EVERY
+    submodule it has by now, so that a state dict loaded straight into a child (`dit.blocks[3].load_state_dict(...)`) also drops
+    the parent's packed copies - the hook registered in the holder's __init__ only sees loads that go through the holder."""
     cache['epoch'] = EPOCH[0]
+    if owner is not None:
+        watch_tree(owner)
     return cache
 
 
@@ -21,7 +26,17 @@ def fresh(cache, device=None, key='device'):
     return cache is not None and cache.get('epoch') == EPOCH[0] and (device is None or cache.get(key) == device)
 
 
+def watch_tree(module):
+    for sub in module.modules():
+        if not sub.__dict__.get('_ln3d_watched', False):
+            sub.register_load_state_dict_post_hook(bump)
+            sub.__dict__['_ln3d_watched'] = True
+    return module
+
+
 def watch(module):
     """Call in the __init__ of a cache-holding module: weights loaded into it (or into a parent) drop every cache."""
-    module.register_load_state_dict_post_hook(bump)
+    if not module.__dict__.get('_ln3d_watched', False):
+        module.register_load_state_dict_post_hook(bump)
+        module.__dict__['_ln3d_watched'] = True
     return module

@@ -49,7 +49,7 @@ class DiT2(nn.Module):
                  'fc1_w': bf16(b.mlp.mlp[0].weight, device), 'fc1_b': f32(b.mlp.mlp[1].bias, device),
                  'fc2_w': bf16(b.mlp.mlp[2].weight, device), 'fc2_b': f32(b.mlp.mlp[3].bias, device)}
             P['blocks'].append(q)
-        self._packed = _cache.stamp(P)
+        self._packed = _cache.stamp(P, self)
         return P
 
     @torch.no_grad()

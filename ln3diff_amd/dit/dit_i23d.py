@@ -79,7 +79,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         P['fin_w'], P['fin_b'] = f32(self.final_layer.linear.weight, device), f32(self.final_layer.linear.bias, device)
         P['fin_sst'] = f32(self.final_layer.scale_shift_table, device)          # [2, D]
         P['zeros'] = torch.zeros(max(D, self.pooling_ctx_dim), device=device)
-        self._packed = _cache.stamp(P)
+        self._packed = _cache.stamp(P, self)
         self._ws = Workspace(device)
 
     def _pack_embedder(self, P, device):

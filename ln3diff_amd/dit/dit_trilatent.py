@@ -126,7 +126,7 @@ class DiT_TriLatent(DiT):
         if _cache.fresh(self._packed, device):
             return
         D = self.embed_dim
-        P = _cache.stamp({'device': device})
+        P = _cache.stamp({'device': device}, self)
         P['pe_w'] = f32(self.x_embedder.proj.weight.reshape(D, -1), device)
         P['pe_b'] = f32(self.x_embedder.proj.bias, device)
         P['pos'] = f32(self.pos_embed[0], device)

@@ -66,6 +66,7 @@ class Triplane(nn.Module):
     def _decoder_dev(self, dev):
         if self._dec is None or self._dec[0].device != dev or self._dec_epoch != _cache.EPOCH[0]:
             self._dec_epoch = _cache.EPOCH[0]
+            _cache.watch_tree(self)
             n = self.decoder.net
             self._dec = tuple(t.detach().to(dev, torch.float32).contiguous()
                               for t in (n[0].weight, n[0].bias, n[2].weight, n[2].bias))

@@ -134,7 +134,7 @@ class FrozenCLIPEmbedder(nn.Module):
                 'fc2_w': bf16(l.mlp.fc2.weight, dev), 'fc2_b': f32(l.mlp.fc2.bias, dev)})
         D = P['tok'].shape[1]
         P['zeros'] = torch.zeros(D, device=dev)
-        self._packed, self._ws = _cache.stamp(P), Workspace(dev)
+        self._packed, self._ws = _cache.stamp(P, self), Workspace(dev)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

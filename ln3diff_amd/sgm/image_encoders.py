@@ -230,6 +230,7 @@ class _ImageEmbedderBase(nn.Module):
             self._runner = _ViTRunner(self._spec(), image.device)
             self._proj_bf = None
             self._epoch = _cache.EPOCH[0]
+            _cache.watch_tree(self)
         return self._runner(self.preprocess(image.float()))
 
 

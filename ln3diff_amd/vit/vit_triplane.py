@@ -153,7 +153,7 @@ class RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout
             P['up'].append(q)
         P['norm_out'] = (f32(d.norm_out.weight, dev), f32(d.norm_out.bias, dev))
         P['conv_out'] = _pack_conv3(d.conv_out, dev)
-        self._packed = _cache.stamp(P)
+        self._packed = _cache.stamp(P, self)
         self._ws = Workspace(dev)
 
     # ------------------------------------------------------------------ conv decoder pieces (channel-last)

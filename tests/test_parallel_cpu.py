@@ -101,3 +101,31 @@ def test_checkpoint_loader_prefixes_and_strictness(tmp_path):
     import pytest
     with pytest.raises(RuntimeError):
         load_checkpoint(f2, dit=m)
+
+
+def test_weight_cache_epoch_bumps_on_every_weight_writer():
+    """ln3diff_amd._cache: packed device copies of the weights are keyed on a global epoch that every in-place weight writer bumps
+    (load_state_dict on a parent or a child, the checkpoint loader, the synthetic filler, invalidate_weight_caches)."""
+    import ln3diff_amd
+    from ln3diff_amd import _cache
+    from ln3diff_amd.dit.dit_trilatent import DiT_TriLatent
+    from ln3diff_amd.synth import fill_module_random_
+    m = DiT_TriLatent(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, context_dim=768, num_classes=0,
+                      learn_sigma=False, roll_out=True)
+    e0 = _cache.EPOCH[0]
+    m.load_state_dict(m.state_dict())
+    e1 = _cache.EPOCH[0]
+    assert e1 > e0
+    _cache.stamp({}, m)                                             # what building the packed copies does (first forward)
+    m.blocks[0].load_state_dict(m.blocks[0].state_dict())          # a CHILD's load must invalidate the parent's packed copies too
+    e2 = _cache.EPOCH[0]
+    assert e2 > e1
+    fill_module_random_(m, 3)
+    e3 = _cache.EPOCH[0]
+    assert e3 > e2
+    ln3diff_amd.invalidate_weight_caches()
+    assert _cache.EPOCH[0] > e3
+    stamp = _cache.stamp({'device': 'cpu'})
+    assert _cache.fresh(stamp, 'cpu')
+    _cache.bump()
+    assert not _cache.fresh(stamp, 'cpu')

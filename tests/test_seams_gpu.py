@@ -152,6 +152,13 @@ def test_weight_caches_follow_load_state_dict(hip_lib):
     assert torch.equal(y1, fresh.cuda()(x, t, c))
     load_synth(m, 0)
     assert torch.equal(m(x, t, c), y0)
+    # a state dict loaded straight into a CHILD module must drop the parent's packed copies as well
+    blk = {k: v.clone() for k, v in fresh.blocks[1].state_dict().items()}
+    m.blocks[1].load_state_dict(blk)
+    ref2, _ = _t23d_tiny()
+    ref2.blocks[1].load_state_dict(blk)
+    y2 = m(x, t, c)
+    assert not torch.equal(y2, y0) and torch.equal(y2, ref2.cuda()(x, t, c))
 
 
 def test_bitwise_determinism(hip_lib):
