@@ -66,11 +66,15 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
             dh = self.embed_dim // self.num_heads
             padw = lambda w: torch.nn.functional.pad(w.detach().float(), (0, attn_head_pad(dh) - dh))     # zero beyond the true head size
-            q['qn'], q['kn'] = f32(padw(b.attn.q_norm.weight), device), f32(padw(b.attn.k_norm.weight), device)
+            has_qk = getattr(b.attn, 'qk_norm', False)
+            q['qn'], q['kn'] = (f32(padw(b.attn.q_norm.weight), device), f32(padw(b.attn.k_norm.weight), device)) if has_qk else (None, None)
             q['proj_w'], q['proj_b'] = bf16(pad_head_columns(b.attn.proj.weight.detach(), self.num_heads, self.embed_dim // self.num_heads), device), f32(b.attn.proj.bias, device)
             q['cq_w'] = bf16(b.cross_attn.to_q.weight, device)
             q['ckv_w'] = bf16(torch.cat([b.cross_attn.to_k.weight, b.cross_attn.to_v.weight], 0), device)
-            q['cqn'], q['ckn'] = f32(b.cross_attn.q_norm.weight, device), f32(b.cross_attn.k_norm.weight, device)
+            has_cqk = getattr(b.cross_attn, 'qk_norm', False)
+            q['cqn'], q['ckn'] = (f32(b.cross_attn.q_norm.weight, device), f32(b.cross_attn.k_norm.weight, device)) if has_cqk else (None, None)
+            if hasattr(b, 'attention_y_norm'):
+                q['ynorm'] = f32(b.attention_y_norm.weight, device)
             q['co_w'], q['co_b'] = bf16(b.cross_attn.to_out[0].weight, device), f32(b.cross_attn.to_out[0].bias, device)
             q['fc1_w'], q['fc1_b'] = bf16(b.mlp.mlp[0].weight, device), f32(b.mlp.mlp[1].bias, device)
             q['fc2_w'], q['fc2_b'] = bf16(b.mlp.mlp[2].weight, device), f32(b.mlp.mlp[3].bias, device)
@@ -121,7 +125,8 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         for i, q in enumerate(P['blocks']):
             ops.gemm(ctx_bf16, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lk, tokens=Lk, tok_pad=lpad,
                      heads=H, head_dim=64, transpose_mask=0b10)
-            ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
+            if q['ckn'] is not None:
+                ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
         return k_all, vt_all, lpad
 
     @torch.no_grad()
@@ -208,11 +213,12 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
                               mod_ld=ld, rows_in=N, rows_out=NA)
             ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
             ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld)
-            if fuse_cq:        # qk_norm of the cross-attention query inside the projection's epilogue
+            if q['cqn'] is not None and fuse_cq:        # qk_norm of the cross-attention query inside the projection's epilogue
                 ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64, head_norm0=q['cqn'])
             else:
                 ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
-                ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
+                if q['cqn'] is not None:
+                    ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
             ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
             ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
             ops.norm_modulate(xt, hb, M, D, kind=1, eps=1e-5, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],
@@ -312,6 +318,65 @@ class DiT_I23D_PixelArt_MVCond_noClip(DiT_I23D_PixelArt):
         k_all, vt_all, lpad = self._cross_kv(mvb, Bn, Lk)
         return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': torch.zeros(Bn, D, device=dev),
                 'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
+
+
+class DiT_TriLatent_PixelArt(DiT_I23D_PixelArt):
+    """T23D DiT with PixArt-style blocks (reference dit/dit_trilatent.py:146-270; registry 'DiT-PixelArt-L/2', 'DiT-PixelArt-B/2'):
+    t = t_embedder + cap_embedder(context['vector']), one shared adaLN + per-block scale_shift_table, PixelArtTextCondDiTBlock
+    (RMSNorm pre-norms, no qk-norm, cross-attention over the text tokens normalised per block), T2IFinalLayer, and the
+    `forward_with_cfg(x, t, context=..., cfg_scale=...)` the flow-matching engine calls - i.e. the T23D denoiser of that engine.
+    Runs on the I23D block machinery: nothing is appended to the self-attention sequence, the per-block normalised context's
+    K / V^T are computed once per prompt."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4,
+                 class_dropout_prob=0.1, num_classes=1000, learn_sigma=True, mixing_logit_init=-3, mixed_prediction=True,
+                 context_dim=False, roll_out=False, vit_blk=None, final_layer_blk=T2IFinalLayer):
+        from .dit_models_xformers import PixelArtTextCondDiTBlock
+        DiT_TriLatent.__init__(self, input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio, class_dropout_prob,
+                               num_classes, learn_sigma, mixing_logit_init, mixed_prediction, context_dim, roll_out,
+                               PixelArtTextCondDiTBlock, T2IFinalLayer)
+        del self.clip_text_proj
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.cap_embedder = nn.Sequential(nn.LayerNorm(context_dim), nn.Linear(context_dim, hidden_size))
+        self.pooling_ctx_dim = context_dim
+        self.clip_ctx_dim = context_dim
+
+    def _append_proj(self):
+        return None
+
+    @torch.no_grad()
+    def prepare_context(self, context):
+        ca, vec = context['crossattn'], context['vector']
+        if ca.shape[-1] != self.clip_ctx_dim or vec.shape[-1] != self.pooling_ctx_dim:
+            raise ValueError(f"context['crossattn'] [B, L, {self.clip_ctx_dim}] text tokens and context['vector'] [B, {self.pooling_ctx_dim}]; "
+                             f"got {tuple(ca.shape)} / {tuple(vec.shape)}")
+        dev = ca.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        Bn, Lc, Cd = ca.shape
+        D, H = self.embed_dim, self.num_heads
+        cls = self._cls_token(vec)
+        lpad = (Lc + 63) // 64 * 64
+        k_all = torch.zeros(self.depth, Bn, H, lpad, 64, dtype=torch.bfloat16, device=dev)
+        vt_all = torch.zeros(self.depth, Bn, H, 64, lpad, dtype=torch.bfloat16, device=dev)
+        caf = ca.contiguous().float()
+        cn = ws.get('ctx_n', (Bn * Lc, Cd), torch.bfloat16)
+        for i, q in enumerate(P['blocks']):
+            ops.norm_modulate(caf, cn, Bn * Lc, Cd, kind=1, eps=1e-5, weight=q['ynorm'])       # the BLOCK's attention_y_norm
+            ops.gemm(cn, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad, heads=H, head_dim=64,
+                     transpose_mask=0b10)
+        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls,
+                'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
+
+
+def DiT_L_TriLatent_Pixelart_2(**kwargs):         # dit_trilatent.py:311-318 ('DiT-PixelArt-L/2')
+    kwargs.pop('vit_blk', None)
+    return DiT_TriLatent_PixelArt(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_B_TriLatent_Pixelart_2(**kwargs):         # dit_trilatent.py:302-309 ('DiT-PixelArt-B/2')
+    kwargs.pop('vit_blk', None)
+    return DiT_TriLatent_PixelArt(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
 
 
 class DiT_pcd_I23D_PixelArt_MVCond(DiT_I23D_PixelArt_MVCond):

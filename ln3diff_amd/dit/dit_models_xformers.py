@@ -159,6 +159,18 @@ class ImageCondDiTBlockPixelArtRMSNorm(DiTBlock):   # dit_models_xformers.py:481
         self.adaLN_modulation = None
 
 
+class PixelArtTextCondDiTBlock(DiTBlock):          # dit_models_xformers.py:326-369
+    """T23D block with PixArt-style conditioning: RMSNorm pre-norms, single shared adaLN + scale_shift_table, cross-attention
+    (64-dim heads, no qk-norm) over the text tokens normalised by the block's own attention_y_norm."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4, context_dim=None, **block_kwargs):
+        super().__init__(hidden_size, num_heads, mlp_ratio, norm_type='rmsnorm')
+        self.cross_attn = MemoryEfficientCrossAttention(query_dim=hidden_size, context_dim=context_dim, heads=num_heads)
+        self.scale_shift_table = nn.Parameter(torch.randn(6, hidden_size) / hidden_size ** 0.5)
+        self.adaLN_modulation = None
+        self.attention_y_norm = RMSNormP(context_dim)
+
+
 class FinalLayer(nn.Module):           # dit_models_xformers.py:655-678
     def __init__(self, hidden_size, patch_size, out_channels):
         super().__init__()

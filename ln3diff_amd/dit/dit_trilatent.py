@@ -303,4 +303,13 @@ def DiT_B_1(**kwargs):          # reference dit_trilatent.py:296-301: no spatial
     return DiT_TriLatent(depth=12, hidden_size=768, patch_size=1, num_heads=12, **kwargs)
 
 
-DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2, 'DiT-B/1': DiT_B_1}
+def _pixart(name):
+    def make(**kwargs):               # the PixArt-style T23D class lives with the I23D block machinery it runs on (import cycle otherwise)
+        from . import dit_i23d
+        return getattr(dit_i23d, name)(**kwargs)
+    make.__name__ = name
+    return make
+
+
+DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2, 'DiT-B/1': DiT_B_1,
+              'DiT-PixelArt-L/2': _pixart('DiT_L_TriLatent_Pixelart_2'), 'DiT-PixelArt-B/2': _pixart('DiT_B_TriLatent_Pixelart_2')}

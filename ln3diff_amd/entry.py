@@ -82,10 +82,15 @@ def validate(args):
                          "U-Net denoisers are outside the hot path")
     if args.arch_dit_decoder not in DiT2_models:
         raise SystemExit(f"--arch_dit_decoder {args.arch_dit_decoder}: known {sorted(DiT2_models)}")
-    if kind == 'flow' and not args.i23d:
-        raise SystemExit("--trainer_name flow_matching needs an I23D denoiser (--i23d true): the flow-matching engine calls "
-                         "forward_with_cfg(x, t, context=..., cfg_scale=...), which the T23D DiT_TriLatent does not define (in the reference "
-                         "neither: dit/dit_models_xformers.py:915 takes class labels)")
+    pixart_t23d = (not args.i23d) and args.dit_model_arch.startswith('DiT-PixelArt')
+    if kind == 'flow' and not args.i23d and not pixart_t23d:
+        raise SystemExit("--trainer_name flow_matching needs an I23D denoiser (--i23d true) or the PixArt-style T23D one "
+                         "(--dit_model_arch DiT-PixelArt-L/2): the flow-matching engine calls forward_with_cfg(x, t, context=..., "
+                         "cfg_scale=...), which the plain T23D DiT_TriLatent does not define (in the reference neither: "
+                         "dit/dit_models_xformers.py:915 takes class labels)")
+    if pixart_t23d and kind != 'flow':
+        raise SystemExit("--dit_model_arch DiT-PixelArt-* (DiT_TriLatent_PixelArt) is the flow-matching T23D denoiser: use "
+                         "--trainer_name flow_matching")
     if kind == 'gd' and not args.use_ddim and args.unconditional_guidance_scale != 1.0:
         print("[entry] note: p_sample_loop applies no classifier-free guidance (the reference forwards the scale to ddim_sample_loop "
               "only, crossattn_cldm.py:543-547); --unconditional_guidance_scale is ignored without --use_ddim true")

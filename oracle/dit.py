@@ -222,6 +222,34 @@ def t23d_forward(sd, x, timesteps, context, num_heads, patch=2, return_tokens=Fa
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
 
+def t23d_pixart_forward(sd, x, timesteps, context, num_heads, patch=2):
+    """DiT_TriLatent_PixelArt.forward (dit/dit_trilatent.py:146-250; registry 'DiT-PixelArt-L/2' / '-B/2') with
+    PixelArtTextCondDiTBlock (dit_models_xformers.py:326-369): t = t_embedder + cap_embedder(LN -> Linear)(context['vector']), ONE
+    shared adaLN whose output is added to each block's scale_shift_table, RMSNorm (affine, eps 1e-5) pre-norms, self-attention without
+    qk-norm, cross-attention (64-dim heads, no qk-norm) over the text tokens normalised by the BLOCK's attention_y_norm, T2IFinalLayer."""
+    B = x.shape[0]
+    depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    vec = context['vector'].float()
+    cls = linear(layer_norm(vec, 1e-5, sd['cap_embedder.0.weight'], sd['cap_embedder.0.bias']),
+                 sd['cap_embedder.1.weight'], sd['cap_embedder.1.bias'])
+    ctx = context['crossattn'].float()
+    t = t_embedder(sd, timesteps.float()) + cls
+    t0 = linear(F.silu(t), sd['adaLN_modulation.1.weight'], sd['adaLN_modulation.1.bias'])
+    h = patchify_embed(sd, x, patch) + sd['pos_embed']
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        mod = sd[p + 'scale_shift_table'][None] + t0.reshape(B, 6, -1)
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
+        h = h + g_a * self_attention(sd, p + 'attn.', rms_norm(h, sd[p + 'norm1.weight']) * (1 + sc_a) + sh_a, num_heads)
+        h = h + cross_attention(sd, p + 'cross_attn.', h, rms_norm(ctx, sd[p + 'attention_y_norm.weight']), num_heads)
+        h = h + g_m * fused_mlp(sd, p + 'mlp.', rms_norm(h, sd[p + 'norm2.weight']) * (1 + sc_m) + sh_m)
+    shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
+    y = layer_norm(h) * (1 + scale) + shift
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    c_out = y.shape[-1] // (patch * patch)
+    return unpatchify_trilatent(y, B, patch, c_out).float()
+
+
 # --------------------------------------------------------------------- I23D
 def i23d_block(sd, p, x, t0, dino_tok, clip_tok, H):
     B, N, D = x.shape

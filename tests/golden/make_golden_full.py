@@ -194,6 +194,27 @@ def sec_f4():
     save('i23d_mv_xl2', y=y_ref, t=t, manifest=mg.manifest_json(shapes))
     print(f'  (MV-XL/2: {time.time() - t0:.1f}s)')
     del m, sd
+    # T23D with PixArt-style blocks (the class that takes forward_with_cfg(x, t, context=..., cfg_scale=...): T23D flow matching)
+    from dit.dit_trilatent import DiT_TriLatent_PixelArt
+    from dit.dit_models_xformers import T2IFinalLayer
+    for tag, kw, heads, Bp in (('tiny', dict(hidden_size=128, depth=2, num_heads=2, patch_size=2), 2, 2), ('l2', None, 16, 1)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            if kw is None:
+                mp = REF_T['DiT-PixelArt-L/2'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True).eval()
+            else:
+                mp = DiT_TriLatent_PixelArt(input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                                            final_layer_blk=T2IFinalLayer, **kw).eval()      # as the registry functions construct it
+        sdp, shapes = load_synth(mp, 0)
+        xp = synth_input('x', (2 * Bp, 12, 32, 32), 3)
+        tp_ = torch.tensor([0.35] * (2 * Bp))
+        cp = {'crossattn': synth_input('c', (2 * Bp, 77, 768), 3), 'vector': synth_input('v', (2 * Bp, 768), 3)}
+        y_ref = mp.forward_with_cfg(xp, tp_, cp, 4.0)
+        eps = odit.t23d_pixart_forward(sdp, xp, tp_, cp, heads)
+        c_, u_ = torch.split(eps, len(eps) // 2, dim=0)
+        half = u_ + 4.0 * (c_ - u_)
+        check(f'DiT_TriLatent_PixelArt {tag} forward_with_cfg', torch.cat([half, half]), y_ref)
+        save(f't23d_pixart_{tag}', y=y_ref, t=tp_, manifest=mg.manifest_json(shapes))
+        del mp, sdp
     # point-cloud latent variant: tiny (class semantics) and the registry size ('DiT-PixArt-MV-PCD-L': depth 24, hidden 1024)
     from dit.dit_i23d import DiT_pcd_I23D_PixelArt_MVCond
     for tag, kw, heads in (('tiny', dict(hidden_size=128, depth=2, num_heads=2, patch_size=1), 2), ('l', None, 16)):

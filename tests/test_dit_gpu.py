@@ -61,3 +61,24 @@ def test_t23d_full_vs_golden(hip_lib, arch, B, tag):
     y2 = m(x.cuda() * 2.0, torch.cat([t, t]).cuda(), context_cache=cc,
            in_scale=torch.full((2 * B,), 0.5, device='cuda')).cpu()
     assert rel_l2(y2[:B], y) < 1e-3 and rel_l2(y2[B:], y) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ['tiny', 'l2'])
+def test_t23d_pixart_forward_with_cfg_vs_reference_golden(hip_lib, tag):
+    """DiT_TriLatent_PixelArt (dit_trilatent.py:146-270; 'DiT-PixelArt-L/2'): the T23D denoiser of the flow-matching engine."""
+    from ln3diff_amd.dit.dit_trilatent import DiT_models
+    from ln3diff_amd.dit.dit_i23d import DiT_TriLatent_PixelArt
+    from ln3diff_amd.synth import synth_input
+    g = golden(f't23d_pixart_{tag}')
+    kw = dict(input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True)
+    m = DiT_models['DiT-PixelArt-L/2'](**kw) if tag == 'l2' else DiT_TriLatent_PixelArt(hidden_size=128, depth=2, num_heads=2, patch_size=2, **kw)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    B2 = int(g['y'].shape[0])
+    x = synth_input('x', (B2, 12, 32, 32), 3).cuda()
+    ctx = {'crossattn': synth_input('c', (B2, 77, 768), 3).cuda(), 'vector': synth_input('v', (B2, 768), 3).cuda()}
+    y = m.forward_with_cfg(x, torch.from_numpy(g['t']).cuda(), ctx, 4.0).cpu()
+    e = rel_l2(y, g['y'])
+    print('t23d pixart', tag, e)
+    assert e < 2e-2, e

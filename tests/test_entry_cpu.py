@@ -31,7 +31,8 @@ def test_reference_launcher_flags_parse():
     (("--i23d", "true", "--dit_model_arch", "DiT-L/2", "--trainer_name", "flow_matching"), "T23D architecture"),
     (("--i23d", "true", "--dit_model_arch", "DiT-PixArt-L/2"), "flow-matching"),         # I23D with the EDM engine
     (("--trainer_name", "no_such"), "known engines"),
-    (("--trainer_name", "flow_matching"), "needs an I23D denoiser"),                     # T23D arch with the flow-matching engine
+    (("--trainer_name", "flow_matching"), "needs an I23D denoiser"),
+    (("--dit_model_arch", "DiT-PixelArt-L/2"), "flow-matching T23D denoiser"),           # PixArt T23D with the EDM engine                     # T23D arch with the flow-matching engine
     (("--create_controlnet", "true"), "ControlNet"),
     (("--arch_dit_decoder", "DiT2-Z/9"), "arch_dit_decoder"),
     (("--num_samples", "0"), ">= 1"),
