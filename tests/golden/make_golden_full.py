@@ -2,7 +2,7 @@
 """Full-size golden vectors (VERDICT r1 "weak" item 1): sequential parity at the benchmarked model sizes, produced by the
 REFERENCE's own Python in the build container (see make_golden.py for the rules; the reference does not travel).
 
-    python tests/golden/make_golden_full.py [full_edm] [full_flow] [render_full] [chain]
+    python tests/golden/make_golden_full.py [full_edm] [full_flow] [render_full] [chain] [f4]
 
   full_edm    DiT-L/2 T23D, EulerEDMSampler(250) + DiscreteDenoiser + VanillaCFG(6.5), B = 1 (network batch 2): final
               latent and three trajectory points.  ~2 x 8 min on 8 cores (reference + oracle).
@@ -11,6 +11,8 @@ REFERENCE's own Python in the build container (see make_golden.py for the rules;
   chain       BASELINE configs[1] end to end on the tiny models (a20): z(seed 41) -> EulerEDM(10)+CFG -> latent * 0.96806 ->
               AE(behaviour='decode_after_vae_no_render') -> AE(behaviour='triplane_dec') for 2 cameras @ 32^2, and
               AE(behaviour='triplane_decode_grid', grid_size=8): what render_video_given_triplane drives.
+  f4          the registry variants beyond the two released models, each against the reference CLASS: DiT-B/1, DiT-PixArt-MV-XL/2,
+              DiT_TriLatent_PixelArt (tiny + 'DiT-PixelArt-L/2'), DiT_pcd_I23D_PixelArt_MVCond (tiny + 'DiT-PixArt-MV-PCD-L').
 """
 import contextlib
 import io
