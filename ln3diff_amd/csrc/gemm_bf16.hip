@@ -259,6 +259,16 @@ struct RunEpi {
       }
     }
   }
+  // GATE_RES with the residual quad already in registers (staged_epilogue prefetches the 8 rows of a block in one batch)
+  __device__ __forceinline__ void apply_res(const GemmP& p, int tb, int row, int fb, float4 v, float4 x) const {
+    const float4 g = row >= grows_left ? g1 : g0;
+    x.x += (v.x + bias.x) * g.x; x.y += (v.y + bias.y) * g.y; x.z += (v.z + bias.z) * g.z; x.w += (v.w + bias.w) * g.w;
+    *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb) = x;
+    if (p.out1) {
+      uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
+      *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)(tb + row) * p.ldo + fb) = o;
+    }
+  }
   __device__ __forceinline__ void apply(const GemmP& p, int tb, int row, int fb, float4 v) const {
     if constexpr (EPI == LN3D_EPI_HEADS) {
       if (generic) { epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w); return; }
@@ -295,13 +305,78 @@ struct RunEpi {
   }
 };
 
-template <int EPI, int NI, int NJ>
+template <int EPI, int NI, int NJ, bool DBUF = true>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
   constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
   constexpr bool kBf16Out = kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_CROSS_ATTN;
   const bool wide = kBf16Out && (p.N & 7) == 0 && (p.ldo & 7) == 0;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rrow = lane >> 4, rc = lane & 15;
+  // GATE_RES: the fp32 residual rows of a 32-token block (8 quads per lane) are fetched as ONE batch, a block ahead of their
+  // use when the register budget allows (DBUF).  r2 read each quad right before its own store: out0 is both loaded and stored,
+  // so hipcc kept every load behind the previous row's store - 24 dependent round trips to L2 / the fabric per wave
+  // (global_load, s_waitcnt vmcnt(0), global_store, ...), measured as +10 us on the attention-projection GEMM.
+  constexpr int NBLK = (NI / 2) * NJ;
+  float4 xres[2][DBUF ? 8 : 1];
+  auto prefetch_res = [&](int blk, float4 (&xr)[DBUF ? 8 : 1]) __attribute__((always_inline)) {
+    const int fb_ = fw0 + (blk / NJ) * 64 + 4 * rc;
+    const int tb_ = tw0 + (blk % NJ) * 32;
+#pragma unroll
+    for (int it = 0; it < (DBUF ? 8 : 1); ++it) {
+      const int row = 4 * it + rrow;
+      xr[it] = (tb_ + row < p.M && fb_ < p.N) ? *reinterpret_cast<const float4*>((const float*)p.out0 + (int64_t)(tb_ + row) * p.ldo + fb_)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if constexpr (EPI == LN3D_EPI_GATE_RES && DBUF) {
+   if constexpr (NI % 2 == 0) {
+    // Interior tiles (every tile of the DiT shapes): branch-free, so that hipcc's counted vmcnt waits let block b+1's batch
+    // stay in flight while block b is stored (behind exec-masked range checks it falls back to vmcnt(0) per block).
+    const bool full = (tw0 + 32 * NJ <= p.M) && (fw0 + 32 * NI <= p.N) && !(p.gate && p.gate_rows < 32);
+    if (__builtin_amdgcn_readfirstlane(full ? 1 : 0)) {
+      auto fetch = [&](int blk, float4 (&xr)[8]) __attribute__((always_inline)) {
+        const float* base = (const float*)p.out0 + (int64_t)(tw0 + (blk % NJ) * 32 + rrow) * p.ldo + fw0 + (blk / NJ) * 64 + 4 * rc;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) xr[it] = *reinterpret_cast<const float4*>(base + (int64_t)(4 * it) * p.ldo);
+      };
+      constexpr bool TWO = NI * NJ <= 6;                 // 128 accumulators (256x256 tile) leave room for one batch only
+      // bias / gate quads of a block are requested BEFORE its residual batch: whatever wait hipcc puts behind them (they
+      // sit in conditionals) then covers only the previous batch, which the block being stored needs anyway
+      auto blk_fb = [&](int blk) __attribute__((always_inline)) { return fw0 + (blk / NJ) * 64 + 4 * rc; };
+      auto blk_tb = [&](int blk) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tw0 + (blk % NJ) * 32); };
+      RunEpi<EPI> re_cur, re_nxt;
+      re_cur.init(p, blk_fb(0), blk_tb(0), 0, 0, 0);
+      fetch(0, xres[0]);
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk) {
+        const int ih = blk / NJ, j = blk % NJ;
+        const int fb = blk_fb(blk);
+        const int tb = blk_tb(blk);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = ii * 8 + 2 * g + hi;
+            *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
+                make_float4(acc[2 * ih + ii][j][4 * g + 0], acc[2 * ih + ii][j][4 * g + 1], acc[2 * ih + ii][j][4 * g + 2], acc[2 * ih + ii][j][4 * g + 3]);
+          }
+        if constexpr (TWO) {
+          if (blk + 1 < NBLK) { re_nxt.init(p, blk_fb(blk + 1), blk_tb(blk + 1), 0, 0, 0); fetch(blk + 1, xres[(blk + 1) & 1]); }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = 4 * it + rrow;
+          const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+          re_cur.apply_res(p, tb, row, fb, v, xres[TWO ? (blk & 1) : 0][it]);
+        }
+        if constexpr (TWO) re_cur = re_nxt;
+        else if (blk + 1 < NBLK) { re_cur.init(p, blk_fb(blk + 1), blk_tb(blk + 1), 0, 0, 0); fetch(blk + 1, xres[0]); }
+      }
+      return;
+    }
+   }
+    prefetch_res(0, xres[0]);
+  }
 #pragma unroll
   for (int ih = 0; ih < NI / 2; ++ih) {
     const int fb = fw0 + ih * 64 + 4 * rc;
@@ -368,6 +443,42 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
             u32x4_t ov = {o.x, o.y, o.z, o.w};
             u32x4_t* dstp = reinterpret_cast<u32x4_t*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + f8);
             __builtin_nontemporal_store(ov, dstp);   // streaming store: the activations are read once, by the next kernel (fc1 -3 us, within box noise)
+          }
+        }
+      } else if constexpr (EPI == LN3D_EPI_GATE_RES) {
+        constexpr int DB = DBUF ? 1 : 0;
+        const int blk = ih * NJ + j;                     // compile-time after unrolling
+        if constexpr (DBUF) {
+          if (blk + 1 < NBLK) prefetch_res(blk + 1, xres[(blk + 1) & DB]);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = 4 * it + rrow;
+            const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+            if (tb + row < p.M && fok) {
+              if (re.generic) epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w);
+              else re.apply_res(p, tb, row, fb, v, xres[blk & DB][it]);
+            }
+          }
+        } else {
+          // 3 waves per SIMD (168 VGPRs): batches of 4 rows
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            float4 xr[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = 4 * (4 * hb + it) + rrow;
+              xr[it] = (tb + row < p.M && fok) ? *reinterpret_cast<const float4*>((const float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = 4 * (4 * hb + it) + rrow;
+              const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+              if (tb + row < p.M && fok) {
+                if (re.generic) epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w);
+                else re.apply_res(p, tb, row, fb, v, xr[it]);
+              }
+            }
           }
         }
       } else {
@@ -792,7 +903,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     return;
   }
   __builtin_amdgcn_s_barrier();
-  staged_epilogue<EPI, NI, NJ>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
+  staged_epilogue<EPI, NI, NJ, (NW <= 8)>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
 }
 
 template <int EPI, int NW, int WGT, int NI, int NJ>

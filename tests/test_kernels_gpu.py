@@ -219,6 +219,40 @@ def test_attention_streaming_kernel_shapes(ops, B, H, Nq, Nk):
     assert e < 1e-2, e
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,spike", [(16, 16, 768, 768, 4.0), (16, 16, 768, 768, 40.0), (32, 8, 512, 512, 40.0), (19, 14, 768, 512, 3.0),
+                                             (16, 16, 256, 768, 40.0)])
+def test_attention_k_resident_kernel(ops, B, H, Nq, Nk, spike):
+    """attn_kres_kernel (Dh 64, Nk 512 / 768, Nq a multiple of 256, a head for every CU = the benchmarked DiT-L/2 geometry,
+    network batch 16 x 16 heads): K resident in LDS, row sums on the matrix pipe, fixed reference per query block.  spike 40:
+    one key per head scores ~2^340 above the reference of its row, which overflows the fast path, is detected through the row
+    sum and recomputed exactly in-kernel (only every third head is spiked, so both paths run in one launch); an early-tile spike
+    makes every other score of a row underflow.  Compared with fp32 softmax attention on the same bf16 operands, bit-repeatable."""
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(Nq * 13 + Nk + B)
+    q = torch.randn(B, H, Nq, 64, generator=g) * 1.5
+    k = torch.randn(B, H, Nk, 64, generator=g) * 1.5
+    v = torch.randn(B, H, Nk, 64, generator=g) + torch.arange(64) / 64
+    k[:, ::3, Nk - 37] = q[:, ::3, 5] * spike                  # late key: far above the first tile's maximum
+    k[:, 1::3, Nk // 2 + 3] = q[:, 1::3, Nq - 2] * 4.0
+    k[:, :, 11] = q[:, :, Nq - 1] * spike                        # first tile: the reference itself is the spike
+    qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
+    vt = vb.transpose(-1, -2)[..., ops.vt_key_order(Nk, dev)].contiguous()
+    outs = []
+    for _ in range(2):
+        out = torch.empty(B, Nq, H * 64, device=dev, dtype=torch.bfloat16)
+        ops.attention(qb, kb, vt, out, B, H, Nq, Nq, Nk, Nk, 64)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0].float()).all()
+    ref = _attn_ref(qb, kb, vb, 64 ** -0.5).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
+    e = rel_l2(outs[0].float(), ref)
+    assert e < 1e-2, e
+    # the spiked rows themselves (softmax ~ one-hot): row 5 of every third head must equal V of the spiked key
+    row = outs[0].float().view(B, Nq, H, 64)[:, 5, ::3]
+    tgt = vb.float()[:, ::3, Nk - 37]
+    assert rel_l2(row, tgt) < 1e-2
+
+
 @pytest.mark.parametrize("D,kind", [(128, 0), (768, 0), (1024, 0), (1152, 0), (1024, 1)])
 def test_norm_modulate(ops, D, kind):
     dev = 'cuda'

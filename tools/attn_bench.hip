@@ -1,8 +1,10 @@
 // Stand-alone self-checking benchmark of ln3d_attention_bf16 (GPU box; build in the container, the binary ships with gpurun):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/attn_bench.hip -o build/attn_bench && build/attn_bench
-// For every case the kernel variants (LN3D_ATTN_V / LN3D_ATTN_NW measurement switches of csrc/attention.hip) are timed with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/attn_bench.hip -o build/attn_bench && build/attn_bench
+// For every case the kernel variants (the measurement switches of csrc/attention.hip, set directly in g_attn_cfg) are timed with
 // HIP events on random data and their output is compared, element by element, with a naive fp32 kernel on the SAME bf16
-// operands.  One key row is spiked against one query row per head so the deferred-rebase branch is exercised.
+// operands.  Per head one key row is spiked against one query row: x3 (a score ~2^26 above the rest: the deferred-rebase branch
+// of the r1 / r2 kernels) or, in every third head, x40 (~2^346: overflows the fixed reference of attn_kres_kernel, so its
+// exact recomputation path runs); heads with bh % 5 == 1 carry the spike in the FIRST tile instead (everything else underflows).
 #include "../ln3diff_amd/csrc/attention.hip"
 #include <cmath>
 #include <cstdio>
@@ -37,13 +39,15 @@ __global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, f
 static uint16_t f2bf_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float frand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xffffff) / 8388608.0f - 1.0f; }
 
-struct Case { int B, H, Nq, Nk; };
+struct Case { int B, H, Nq, Nk, ovf; };
 
 int main() {
   const int Dh = 64;
-  const Case cases[] = {{16, 16, 768, 768}, {16, 16, 1024, 1024}, {2, 16, 768, 768}, {1, 4, 700, 1000}, {2, 3, 300, 832}, {1, 2, 257, 257}};
-  const struct { const char* name; const char* v; const char* qt; } variants[] = {
-      {"r1 ring kernel", "2", nullptr}, {"stream kernel", "3", nullptr}};
+  const Case cases[] = {{16, 16, 768, 768, 0}, {16, 16, 768, 768, 1}, {16, 16, 1024, 1024, 0}, {32, 16, 512, 512, 1}, {32, 16, 512, 512, 0},
+                        {2, 16, 768, 768, 1}, {1, 4, 700, 1000, 1}, {2, 3, 300, 832, 1}, {1, 2, 257, 257, 1}};
+  const struct { const char* name; int ver, kres; } variants[] = {
+      {"r1 ring kernel", 2, 3}, {"r2 stream kernel", 3, 3}, {"r3 kres", 0, 0}, {"r3 kres +prio", 0, 1}, {"r3 kres +st", 0, 2}, {"r3 kres +prio+st", 0, 3},
+      {"r3 kres2", 0, 4}, {"r3 kres2 +st", 0, 6}};
   const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
   int ci = 0;
   for (const Case& c : cases) {
@@ -59,11 +63,12 @@ int main() {
         const int rp = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
         hv[((size_t)bh * Dh + d) * Nkp + rp] = f2bf_host(frand(seed) + (float)d / Dh);
       }
-      // spike: a late key equal to 3x query row 3 -> its score outgrows every earlier maximum by far more than 2^8
-      const int ks = c.Nk - 5;
+      // spike: a key equal to 3x (every third head: 40x) query row 3
+      const int ks = (bh % 5 == 1) ? 7 : c.Nk - 5;
+      const float fac = (c.ovf && bh % 3 == 0) ? 40.0f : 3.0f;
       for (int d = 0; d < Dh; ++d) {
         uint32_t u = (uint32_t)hq[((size_t)bh * Nqp + 3) * Dh + d] << 16; float f; memcpy(&f, &u, 4);
-        hk[((size_t)bh * Nkp + ks) * Dh + d] = f2bf_host(3.0f * f);
+        hk[((size_t)bh * Nkp + ks) * Dh + d] = f2bf_host(fac * f);
       }
     }
     void *q, *k, *v, *o; float* oref;
@@ -77,16 +82,17 @@ int main() {
     ln3d_attn_args a{};
     a.Q = q; a.K = k; a.Vt = v; a.O = o; a.B = c.B; a.H = c.H; a.Nq = c.Nq; a.Nq_pad = Nqp; a.Nk = c.Nk; a.Nk_pad = Nkp; a.Dh = Dh;
     a.ldo = c.H * Dh; a.scale = 0.125f;
-    printf("B %d H %d Nq %d Nk %d\n", c.B, c.H, c.Nq, c.Nk);
+    printf("B %d H %d Nq %d Nk %d%s\n", c.B, c.H, c.Nq, c.Nk, c.ovf ? "  (x40 spikes: kres recomputes those heads)" : "");
     int vi = 0;
     for (const auto& var : variants) {
       if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
-      if (var.v) setenv("LN3D_ATTN_V", var.v, 1); else unsetenv("LN3D_ATTN_V");
-      if (var.qt) setenv("LN3D_ATTN_QT", var.qt, 1); else unsetenv("LN3D_ATTN_QT");
+      attn_cfg();                                          // environment parsed (once), then overridden per variant
+      g_attn_cfg.ver = var.ver; g_attn_cfg.kres = var.kres;
+      if (var.ver == 0 && var.kres != 6 && !(c.Nk >= 512 && c.Nk <= 768 && (c.Nq & 255) == 0 && c.B * c.H >= 256)) continue;   // same kernel as the default
       hipMemset(o, 0xff, no * 2);
       const int rc = ln3d_attention_bf16(&a, nullptr);
       hipError_t e = hipDeviceSynchronize();
-      if (rc != 0 || e != hipSuccess) { printf("  %-16s FAILED rc %d hip %d\n", var.name, rc, (int)e); return 1; }
+      if (rc != 0 || e != hipSuccess) { printf("  %-18s FAILED rc %d hip %d\n", var.name, rc, (int)e); return 1; }
       std::vector<uint16_t> ho(no), ho2(no);
       hipMemcpy(ho.data(), o, no * 2, hipMemcpyDeviceToHost);
       size_t nd = 0;                                      // determinism: repeated launches must agree bit for bit
@@ -95,7 +101,7 @@ int main() {
         hipMemcpy(ho2.data(), o, no * 2, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < no; ++i) nd += ho[i] != ho2[i];
       }
-      if (nd) printf("  %-16s NONDETERMINISTIC: %zu elements differ over 4 repeats\n", var.name, nd);
+      if (nd) printf("  %-18s NONDETERMINISTIC: %zu elements differ over 4 repeats\n", var.name, nd);
       double num = 0, den = 0, mxe = 0;
       for (size_t i = 0; i < no; ++i) {
         uint32_t u = (uint32_t)ho[i] << 16; float f; memcpy(&f, &u, 4);
@@ -114,7 +120,7 @@ int main() {
         best = fminf(best, ms / 20); sum += ms / 20;
       }
       const double fl = 4.0 * c.Nq * c.Nk * c.H * Dh * c.B;
-      printf("  %-16s rel-L2 %.2e  max|err| %.2e   %8.1f us avg %8.1f us best  %7.1f TF/s (best)\n", var.name, std::sqrt(num / den), mxe,
+      printf("  %-18s rel-L2 %.2e  max|err| %.2e   %8.1f us avg %8.1f us best  %7.1f TF/s (best)\n", var.name, std::sqrt(num / den), mxe,
              sum / 5 * 1e3, best * 1e3, fl / (best * 1e-3) / 1e12);
     }
     hipFree(q); hipFree(k); hipFree(v); hipFree(o); hipFree(oref);
