@@ -47,7 +47,7 @@ int main() {
                         {2, 16, 768, 768, 1}, {1, 4, 700, 1000, 1}, {2, 3, 300, 832, 1}, {1, 2, 257, 257, 1}};
   const struct { const char* name; int ver, kres; } variants[] = {
       {"r1 ring kernel", 2, 3}, {"r2 stream kernel", 3, 3}, {"r3 kres", 0, 0}, {"r3 kres +prio", 0, 1}, {"r3 kres +st", 0, 2}, {"r3 kres +prio+st", 0, 3},
-      {"r3 kres2", 0, 4}, {"r3 kres2 +st", 0, 6}};
+      {"r3 kres2", 0, 4}, {"r3 kres2 +st", 0, 6}, {"r3 kres3 lockstep", 0, 8}, {"r3 kres3 phased", 0, 9}};
   const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
   int ci = 0;
   for (const Case& c : cases) {
