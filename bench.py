@@ -21,7 +21,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_models(dev, arch, dec_arch, seed=0, fill=True):
+def _sha16(rel):
+    import hashlib
+    with open(os.path.join(ROOT, rel), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(key):
+    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r3_pmc.json:
+    FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes; bench.py cannot run the profiler on itself).  An entry is
+    only valid for the kernel source it was measured on: it carries the sha256 of the .hip file, and a different source on disk
+    yields null plus the reason instead of a stale number."""
+    path = os.path.join(ROOT, 'profiles', 'r3_pmc.json')
+    if not os.path.exists(path):
+        return None, 'profiles/r3_pmc.json missing'
+    ent = json.load(open(path)).get(key)
+    if ent is None:
+        return None, 'no PMC entry for %s in profiles/r3_pmc.json' % key
+    cur = _sha16(ent['hip'])
+    if cur != ent['sha16']:
+        return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/pmc_traffic.sh' % (ent['hip'], cur, ent['sha16'])
+    return ent['traffic_bytes'], ent['source']
+
+
+def build_models(dev, arch, dec_arch, seed=0, fill=True, golden_weights=False):
     from ln3diff_amd.dit.dit_trilatent import DiT_models
     from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
     from ln3diff_amd.dit.dit_decoder import DiT2_models
@@ -37,7 +60,11 @@ def build_models(dev, arch, dec_arch, seed=0, fill=True):
               ldm_z_channels=4, ldm_embed_dim=4)
     dit, dec = dit.to(dev), dec.to(dev)
     if fill:
-        fill_module_random_(dit, seed, dev)
+        if golden_weights:            # the (name, shape, seed) weights of tests/golden: lets the timed run be checked against a golden
+            from ln3diff_amd.synth import load_synth_
+            load_synth_(dit, seed)
+        else:
+            fill_module_random_(dit, seed, dev)
         fill_module_random_(dec, seed + 1, dev)
         # keep the synthetic volume non-empty so compositing is exercised
         dec.triplane_decoder.decoder.net[2].bias.data[0] += 4.0
@@ -65,12 +92,9 @@ def roofline_probe(dev, n_net, D, iters=20, tokens=768):
     flops = 2.0 * M * N * K
     peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
     ach = flops / (ms * 1e-3) / 1e12
-    # traffic: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch of this kernel at this shape, from the separate
-    # rocprofv3 --pmc passes committed in profiles/r2_e_pmc.md (bench.py cannot run the profiler on itself)
-    traffic = 277.5e6 if (M, N, K) == (12288, 4096, 1024) else None
+    traffic, src = pmc_traffic("gemm_fc1_gelu_%dx%dx%d" % (M, N, K))
     return {"kernel": "gemm_bf16_ring64_kernel<GELU_ERF, 256x256> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-            "traffic_source": "profiles/r2_e_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate --pmc passes)", "avg_us": round(ms * 1e3, 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src, "avg_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops}
 
 
@@ -92,11 +116,13 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * Nq * N * H * Dh * n_net          # 4*Nq*Nkv*(H*Dh) per sample-layer
     ach = flops / (ms * 1e-3) / 1e12
-    stream = (N % 256 == 0 and Dh == 64 and not os.environ.get('LN3D_ATTN_V'))
-    return {"kernel": ("attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<64,4>") +
-                      " - DiT self-attention, %d queries x %d keys" % (Nq, N), "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
-            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": 230.9e6 if (N == 768 and Nq == 768 and n_net == 16 and H == 16) else None,
-            "traffic_source": "profiles/r2_e_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE; K / V^T re-reads miss the 4 MB XCD L2: 11.8 % hits), profiles/r2_attn_pmc.md (instruction-issue bound)"}
+    kres = (N % 256 == 0 and 512 <= N <= 768 and Nq % 256 == 0 and Dh == 64 and n_net * H >= 256 and os.environ.get('LN3D_ATTN_V') in (None, '', '4'))
+    stream = (N % 256 == 0 and Dh == 64 and not kres and os.environ.get('LN3D_ATTN_V') != '2')
+    name = ("attn_kres_kernel (K resident in LDS, V^T ring, row sums on the matrix pipe)" if kres else
+            "attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<64,4>")
+    traffic, src = pmc_traffic("attention_%dx%dx%dx%d" % (n_net * H, Nq, N, Dh))
+    return {"kernel": name + " - DiT self-attention, %d queries x %d keys" % (Nq, N), "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": traffic, "traffic_source": src}
 
 
 def render_probe(dev, dec, res=256, V=4, iters=5):
@@ -127,79 +153,100 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
             "definition": "algorithmic gather bytes (1536 B/sample point) / time; the texels are L2-resident so this is an L2-gather "
                           "rate, not HBM traffic - judge the kernel on ms_per_view vs target_ms_per_view",
             "ms_per_view": round(ms / V, 3), "target_ms_per_view": 2.7, "mlp_issued_bf16_tflops": round(mlp_tflops, 1),
-            "traffic": 0.39e9 if (V, res) == (4, 256) else None,
-            "traffic_source": "profiles/r2_render_pmc.md (FETCH_SIZE x 2 + WRITE_SIZE of one 4-view launch: 0.12 TB/s - not an HBM-bound kernel)"}
+            "traffic": pmc_traffic("render_%dx%d" % (V, res))[0], "traffic_source": pmc_traffic("render_%dx%d" % (V, res))[1]}
 
 
-def cpu_baseline(arch, steps_total, views, res, B):
-    """CPU restatement (oracle/, validated against the reference's own Python in the build container) timed on
-    this box's host cores on a bounded sample of the same workload, extrapolated linearly (per-step and per-view
-    costs are constant): 2 timed EulerEDM steps at B=1 (network batch 2, CFG), 1 VAE decode scaled by FLOPs, 1 view."""
-    from oracle import dit as odit, samplers as osamp, render as orender
-    from ln3diff_amd.synth import orbit_cameras
-    from ln3diff_amd.dit.dit_trilatent import DiT_models
-    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
-    # SURVEY 8d: "all host cores, count stated".  torch's CPU kernels get SLOWER past the socket's sweet spot on the 256-thread
-    # GPU hosts (141 s per DiT-L/2 step with 256 threads vs ~10 s with 32), so the thread count is calibrated on a GEMM of the
-    # workload's shape and the best one is used and reported; `host_cores` states what the box has.
+def _pick_threads():
+    """"all host cores, count stated".  torch's CPU kernels get SLOWER past the socket's sweet spot on the 256-thread GPU
+    hosts (141 s per DiT-L/2 step with 256 threads vs ~2.4 s with 32), so three thread counts are probed on a GEMM + GELU of the
+    workload's shape, the best one is used, and all three timings are reported."""
     host = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     xa, wa = torch.randn(1536, 1024), torch.randn(4096, 1024)
-    best = None
-    for n in sorted({min(host, c) for c in (8, 16, 32, 64, 128, host)}):
+    probe = {}
+    for n in sorted({max(1, min(host, c)) for c in (16, 32, 64)}):
         torch.set_num_threads(n)
         torch.nn.functional.linear(xa, wa)
         t0 = time.time()
         for _ in range(5):
             torch.nn.functional.gelu(torch.nn.functional.linear(xa, wa))
-        dt = time.time() - t0
-        if best is None or dt < best[1]:
-            best = (n, dt)
-    cores = best[0]
+        probe[n] = round((time.time() - t0) / 5 * 1e3, 2)
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    hidden, depth, heads = odit.DIT_CONFIGS[arch]
+    return cores, host, probe
+
+
+def _cpu_view(res_target, g):
+    """One view of the oracle's renderer at 64^2, scaled by the ray count (the cost is linear in rays)."""
+    from oracle import render as orender
+    from ln3diff_amd.synth import orbit_cameras
+    dec_sd = {'net.0.weight': torch.randn(64, 32, generator=g), 'net.0.bias': torch.zeros(64),
+              'net.2.weight': torch.randn(4, 64, generator=g), 'net.2.bias': torch.tensor([4., 0, 0, 0])}
+    planes = torch.randn(1, 96, 128, 128, generator=g) * 4
+    rr = min(res_target, 64)
+    jit = torch.rand(1, rr * rr, 64, 1, generator=g)
+    uf = torch.rand(rr * rr, 64, generator=g)
+    t0 = time.time()
+    orender.triplane_render(planes, dec_sd, orbit_cameras(1), rr, jit, uf)
+    return (time.time() - t0) * (res_target / rr) ** 2, rr
+
+
+def cpu_baseline(arch, steps_total, views, res, B, i23d=False):
+    """CPU restatement (oracle/, validated against the reference's own Python in the build container) timed on this box's host
+    cores on a bounded sample of the same workload and extrapolated linearly (per-step and per-view costs are constant, BASELINE.md
+    2): 1 warm-up + 5 timed network evaluations at B = 1 with CFG (network batch 2) - cut to 2 when a step exceeds 6 s, so the
+    default run stays within its few minutes -, the VAE decode scaled from the step by FLOPs, one view at 64^2 scaled to the
+    target resolution by rays."""
+    from oracle import dit as odit, samplers as osamp
+    cores, host, probe = _pick_threads()
     t_all = time.time()
-    m = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
-                         vit_blk=TextCondDiTBlock)
-    sd = {k: v for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(0)
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2' if i23d else arch]
+    if i23d:
+        from ln3diff_amd.dit.dit_i23d import DiT_models
+        m = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=1024, roll_out=True,
+                             pooling_ctx_dim=768)
+    else:
+        from ln3diff_amd.dit.dit_trilatent import DiT_models
+        from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+        m = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True,
+                             vit_blk=TextCondDiTBlock)
+    sd = {k: v for k, v in m.state_dict().items()}
     for k, v in sd.items():
-        if 'pos_embed' not in k and ('adaLN' in k or 'final_layer' in k):
+        if 'pos_embed' not in k and ('adaLN' in k or 'final_layer' in k or 'scale_shift_table' in k):
             v.copy_(torch.randn(v.shape, generator=g) * 0.02)
     z = torch.randn(1, 12, 32, 32, generator=g)
-    cond = {'crossattn': torch.randn(1, 77, 768, generator=g)}
-    uc = {'crossattn': torch.zeros(1, 77, 768)}
-    table = osamp.discrete_denoiser_table()
-    sig = osamp.legacy_ddpm_sigmas(250)
-    net = lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads)
+    if i23d:
+        zs = torch.cat([z, z])
+        ctx = {'crossattn': torch.cat([torch.randn(1, 256, 2048, generator=g), torch.zeros(1, 256, 2048)]),
+               'vector': torch.cat([torch.randn(1, 768, generator=g), torch.zeros(1, 768)])}
+        step = lambda i: odit.i23d_forward_with_cfg(sd, zs, torch.full((2,), i / 49.0), ctx, 4.0, heads)
+        n_eval, flops_step = steps_total - 1, 2 * 745.0
+    else:
+        cond = {'crossattn': torch.randn(1, 77, 768, generator=g)}
+        uc = {'crossattn': torch.zeros(1, 77, 768)}
+        table = osamp.discrete_denoiser_table()
+        sig = osamp.legacy_ddpm_sigmas(250)
+        net = lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads)
+        step = lambda i: osamp.edm_denoise_cfg(net, z, sig[i:i + 1], cond, uc, 6.5, table)
+        n_eval, flops_step = steps_total, 2 * {'DiT-B/2': 178.0, 'DiT-L/2': 613.0, 'DiT-XL/2': 879.0}.get(arch, 613.0)
     with torch.no_grad():
         t0 = time.time()
-        osamp.edm_denoise_cfg(net, z, sig[:1], cond, uc, 6.5, table)       # first call (includes warm-up effects)
-        t_step = time.time() - t0
-        n_timed = 1
-        if t_step < 8.0:                                                    # bounded: only repeat when it is cheap
-            t0 = time.time()
-            for i in range(2):
-                osamp.edm_denoise_cfg(net, z, sig[i:i + 1], cond, uc, 6.5, table)
-            t_step = (time.time() - t0) / 2
-            n_timed = 2
-        # render: 1 view at a reduced resolution, scaled by ray count (cost is linear in rays)
-        dec_sd = {'net.0.weight': torch.randn(64, 32, generator=g), 'net.0.bias': torch.zeros(64),
-                  'net.2.weight': torch.randn(4, 64, generator=g), 'net.2.bias': torch.tensor([4., 0, 0, 0])}
-        planes = torch.randn(1, 96, 128, 128, generator=g) * 4
-        rr = min(res, 32)
-        jit = torch.rand(1, rr * rr, 64, 1, generator=g)
-        uf = torch.rand(rr * rr, 64, generator=g)
+        step(0)                                                             # warm-up
+        t_warm = time.time() - t0
+        n_timed = 5 if t_warm < 6.0 else 2
         t0 = time.time()
-        orender.triplane_render(planes, dec_sd, orbit_cameras(1), rr, jit, uf)
-        t_view = (time.time() - t0) * (res / rr) ** 2
-    # VAE decode: DiT2-L/2 (734 GFLOP) ~ 1.2x one CFG DiT step (2 x 613 GFLOP) -> scaled from the measured step
-    t_dec = t_step * (734.0 + 20.0) / (2 * 613.0)
-    per_sample = steps_total * t_step + t_dec + views * t_view
+        for i in range(n_timed):
+            step(i + 1)
+        t_step = (time.time() - t0) / n_timed
+        t_view, rr = _cpu_view(res, g)
+    t_dec = t_step * (734.0 + 20.0) / flops_step                            # VAE decode: DiT2-L/2 (734 GFLOP) + conv decoder (~20)
+    per_sample = n_eval * t_step + t_dec + views * t_view
     return {"value": round(1.0 / per_sample, 6), "unit": "3D samples/s", "cores": cores, "host_cores": host, "kind": "port",
-            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads - the fastest of 8..all host cores on a GEMM probe): %d timed EulerEDM+CFG step(s) at B=1 "
-                      "(%.2f s/step) x %d, VAE decode scaled by FLOPs (%.2f s), 1 view at %d^2 scaled to %d^2 "
-                      "(%.2f s/view) x %d views; wall %.0f s" % (cores, n_timed, t_step, steps_total, t_dec, rr, res, t_view,
-                                                                   views, time.time() - t_all)}
+            "thread_probe_ms": {str(k): v for k, v in probe.items()},
+            "sample": "oracle/ (CPU restatement, fp32 torch, %d threads = the fastest of the 3-point probe): 1 warm-up + %d timed %s at B=1 "
+                      "(%.2f s each) x %d, VAE decode scaled by FLOPs (%.2f s), 1 view at %d^2 scaled to %d^2 (%.2f s/view) x %d views; wall %.0f s"
+                      % (cores, n_timed, "forward_with_cfg evaluations" if i23d else "EulerEDM+CFG steps", t_step, n_eval, t_dec, rr, res, t_view,
+                         views, time.time() - t_all)}
 
 
 def _free_port():
@@ -224,14 +271,35 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def build_i23d(dev, arch, seed=0, fill=True):
+def build_i23d(dev, arch, seed=0, fill=True, golden_weights=False):
     from ln3diff_amd.dit.dit_i23d import DiT_models as I23D
-    from ln3diff_amd.synth import fill_module_random_
+    from ln3diff_amd.synth import fill_module_random_, load_synth_
     dit = I23D[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=1024, roll_out=True,
                      pooling_ctx_dim=768).to(dev)
     if fill:
-        fill_module_random_(dit, seed, dev)
+        if golden_weights:
+            load_synth_(dit, seed)
+        else:
+            fill_module_random_(dit, seed, dev)
     return dit
+
+
+def golden_check(latent0, i23d, arch, sample_steps):
+    """Sample 0 of the timed run (global sample 0: the golden's inputs, weights and sampler settings) against the final latent of
+    the reference's own B = 1 loop (tests/golden/full_edm_ditl2_250.npz / full_flow_pixartl2_euler50.npz, made by
+    tests/golden/make_golden_full.py in the build container): what ran at the benchmarked batch geometry IS the reference's
+    computation, not merely something finite.  Only the two baseline configurations have a fixture."""
+    import numpy as np
+    name = ('full_flow_pixartl2_euler50' if (i23d and arch == 'DiT-PixArt-L/2' and sample_steps == 50) else
+            'full_edm_ditl2_250' if (not i23d and arch == 'DiT-L/2' and sample_steps == 250) else None)
+    path = os.path.join(ROOT, 'tests', 'golden', (name or '') + '.npz')
+    if name is None or not os.path.exists(path):
+        return {"fixture": None, "reason": "no golden fixture for this arch / step count"}
+    ref = torch.from_numpy(np.load(path)['final']).double()[0]
+    got = latent0.detach().double().cpu()
+    err = float((got - ref).norm() / ref.norm())
+    return {"fixture": "tests/golden/%s.npz" % name, "what": "final latent of global sample 0 of the LAST timed step vs the reference's B=1 loop",
+            "rel_l2": round(err, 6), "tol": 1e-2, "ok": bool(err < 1e-2)}
 
 
 def main():
@@ -259,7 +327,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
     from ln3diff_amd import parallel
-    from ln3diff_amd.pipeline import T23DPipeline, FlowMatchingEngine, render_video_given_triplane
+    from ln3diff_amd.pipeline import T23DPipeline, FlowMatchingEngine, render_pairs
     from ln3diff_amd.synth import orbit_cameras
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if env_world != args.gpus:                       # before any rendezvous: a mismatched launch must fail, not hang
@@ -275,35 +343,52 @@ def main():
     # rank 0 creates the weights, every rank receives them by ONE flat RCCL broadcast per dtype
     if i23d:
         _, dec = build_models(dev, "DiT-B/2", args.dec_arch, fill=(rank == 0))
-        dit = build_i23d(dev, args.arch, fill=(rank == 0))
+        dit = build_i23d(dev, args.arch, fill=(rank == 0), golden_weights=True)
     else:
-        dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0))
+        dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0), golden_weights=True)
     if world > 1:
         parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] +
                                 [b for b in dec.buffers()], src=0)
     B, Bt = args.batch, args.batch * world
     g = torch.Generator(device=dev).manual_seed(42 if i23d else 41)            # global seed, full batch, then sliced per rank
     z_all = torch.randn(Bt, 12, 32, 32, device=dev, generator=g)
+    from ln3diff_amd.synth import synth_input
+    gseed = 42 if i23d else 41                                                  # global sample 0 = the golden's sample (inputs from synth_input)
+    z_all[0] = synth_input('z', (1, 12, 32, 32), gseed)[0].to(dev)
     lo, hi = parallel.shard_range(Bt, rank, world)
     cams = orbit_cameras(args.views).to(dev)
     if i23d:
         eng = FlowMatchingEngine(dit, dec)
         c_all = {'crossattn': torch.randn(Bt, 256, 2048, device=dev, generator=g), 'vector': torch.randn(Bt, 768, device=dev, generator=g)}
+        c_all['crossattn'][0] = synth_input('ca', (1, 256, 2048), gseed)[0].to(dev)
+        c_all['vector'][0] = synth_input('v', (1, 768), gseed)[0].to(dev)
         cond = {k: v[lo:hi].contiguous() for k, v in c_all.items()}
 
-        def one_step():
-            latent = eng.sample(cond, None, batch_size=hi - lo, cfg_scale=4.0, num_steps=args.sample_steps, zs=z_all[lo:hi].clone())
-            img = render_video_given_triplane(latent.clone(), eng.rec_model, cams, eng.triplane_scaling_divider, resolution=args.res)
-            return parallel.all_gather_cat(latent), img
+        def sample_fn(lo_, hi_):
+            if hi_ <= lo_:
+                return torch.empty(0, 12, 32, 32, device=dev)
+            return eng.sample(cond, None, batch_size=hi_ - lo_, cfg_scale=4.0, num_steps=args.sample_steps, zs=z_all[lo_:hi_].clone())
     else:
         c_all = torch.randn(Bt, 77, 768, device=dev, generator=g)
+        c_all[0] = synth_input('c', (1, 77, 768), gseed)[0].to(dev)
         cond = {'crossattn': c_all[lo:hi].contiguous()}
         uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
         pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
 
-        def one_step():
-            latent, img = pipe(z_all[lo:hi].clone(), cond, uc, cams, args.res)
-            return parallel.all_gather_cat(latent), img
+        eng = pipe
+
+        def sample_fn(lo_, hi_):
+            if hi_ <= lo_:
+                return torch.empty(0, 12, 32, 32, device=dev)
+            return pipe.sample_latent(z_all[lo_:hi_].clone(), cond, uc)
+
+    # One step = parallel.sharded_step: this rank's samples are denoised, ONE all_gather of the latents, then this rank's share of
+    # the B x V (sample, view) pairs is decoded + rendered (with B >= ranks: the views of its own samples).
+    def one_step():
+        lat_all, frames, _ = parallel.sharded_step(
+            sample_fn, lambda la, pairs: render_pairs(la, eng.rec_model, cams, pairs, eng.triplane_scaling_divider, resolution=args.res),
+            Bt, args.views, rank, world)
+        return lat_all, frames
 
     for _ in range(args.warmup):
         out = one_step()
@@ -348,6 +433,7 @@ def main():
             "config": {"workload": wl, "global_batch": Bt, "views": args.views, "res": args.res,
                        "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
             "finite": ok,
+            "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps),
         }
         if not args.no_probes:
             D = dit.embed_dim
@@ -364,8 +450,8 @@ def main():
                 r["frac"] = round(r["achieved"] / r["peak"], 4)
             rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 1024 if i23d else 768, D // dit.num_heads, Nq=768)
             rec["roofline_raymarch"] = render_probe(dev, dec)
-        if not args.no_cpu_baseline and world == 1 and not i23d:
-            rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B)
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B, i23d=i23d)
         print(json.dumps(rec), flush=True)
     parallel.barrier()
 

@@ -52,9 +52,22 @@ DECODER_PREFIXES = ("rec_model.decoder.", "auto_encoder.decoder.", "decoder.", "
 CONDITIONER_PREFIXES = ("conditioner.embedders.0.", "cond_stage_model.", "")
 
 
-def load_checkpoint(path, dit=None, decoder=None, conditioner=None, strict=True):
+def covers(sd, module, prefixes):
+    """How many of the module's tensors the file holds under any of the prefixes (0: the file does not contain this component)."""
+    own = module.state_dict()
+    return sum(1 for k in own if any((p + k) in sd for p in prefixes))
+
+
+def load_checkpoint(path, dit=None, decoder=None, conditioner=None, strict=True, skip_absent=False):
+    """skip_absent: a component none of whose tensors is in the file is left alone (reported as absent) instead of raising - the
+    joint `--resume_checkpoint` files hold denoiser AND decoder, the `--ddpm_model_path` / `--rec_model_path` ones only one."""
     sd = read_state_dict(path)
     rep = {}
+    if skip_absent:
+        if dit is not None and covers(sd, dit, DIT_PREFIXES) == 0:
+            rep['dit'], dit = 'absent', None
+        if decoder is not None and covers(sd, decoder, DECODER_PREFIXES) == 0:
+            rep['decoder'], decoder = 'absent', None
     if dit is not None:
         rep['dit'] = load_into(dit, sd, DIT_PREFIXES, strict)
     if decoder is not None:

@@ -603,8 +603,11 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
 // Per 32-key tile and wave: 10 MFMAs (4 S^T, 4 PV, 2 row-sum) against 16 v_exp + 8 v_cvt_pk + 8 ds_read_b128.
 // Counted waits: vmcnt counts LDS-DMA loads and global stores in issue order (gfx9 has one counter for both); every wait below
 // is "at most W younger requests outstanding", W derived in top_of_step from what was issued behind the request it needs.
-#ifndef LN3D_KRES_ORDER
-#define LN3D_KRES_ORDER 2
+#ifndef LN3D_KRES_ORDER   // 0: S^T chain spread between the PV MFMAs, 1: S^T chain back to back, 2: PV of keys 0-15 first (r3: 54.8 / 50.3 / 51.3 us)
+#define LN3D_KRES_ORDER 1
+#endif
+#ifndef LN3D_KRES_PIN     // 1: pin the order of the pieces with sched_barrier; 0: hipcc's own interleave of the same pieces (r3: 50.3 vs 49.0 us)
+#define LN3D_KRES_PIN 0
 #endif
 #ifndef LN3D_KRES_ABL   // tools/attn_bench.hip builds with -DLN3D_KRES_ABL=bits (wrong results by construction): 1 no v_exp, 2 no MFMA,
 #define LN3D_KRES_ABL 0  // 4 no barrier / DMA wait, 8 no fragment reads, 16 no DMA issue in the stream, 32 hipcc's own instruction order
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void attn_kres_kernel(AttnP p) {
     // The instruction order is pinned (sched_barrier between the pieces): an in-order wave issues ~7 VALU under one 32-cycle
     // MFMA, and the four S^T MFMAs are one dependent chain, so they alternate with the independent PV / row-sum MFMAs and the
     // exps sit where an MFMA is in flight.  hipcc's own order put the first S^T MFMA (and a wait for all 8 reads) first.
-#define SB_ do { if constexpr (!(LN3D_KRES_ABL & 32)) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SB_ do { if constexpr (LN3D_KRES_PIN && !(LN3D_KRES_ABL & 32)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define EXP_(x_) ((LN3D_KRES_ABL & 1) ? (x_) : __builtin_amdgcn_exp2f(x_))
 #define MFMA_(a_, b_, c_) ((LN3D_KRES_ABL & 2) ? abl_nomfma(a_, b_, c_) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0))
     f32x16 zc;
@@ -1051,761 +1054,6 @@ __global__ __launch_bounds__(512, 2) void attn_kres_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K-resident kernel, third form: 8 waves x 32 queries like attn_kres_kernel, but every half-step is split into a V phase
-// (fragment reads + the 16 exps / 8 packs of the current tile) and an M phase (10 MFMAs back to back: S^T of the next tile, PV
-// and row sums of the current one), and with PHASED the per-step barrier of waves 4-7 sits one phase later in their stream
-// (between the V and the M phase of a step's second tile instead of behind the M phase).  The two waves of a SIMD - one of
-// waves 0-3 and one of waves 4-7 - then leave every barrier in opposite phases: one starts with exps while the other starts
-// with MFMAs, instead of both hitting the LDS, the VALU and the matrix pipe at the same moment (the r3 ablations:
-// every cost of the lock-stepped kernel was additive).  No softmax reference (see attn_kres2_kernel), O stores not counted
-// in the waits (always safe).
-#ifndef LN3D_KRES3_ABL
-#define LN3D_KRES3_ABL 0
-#endif
-template <bool PHASED>
-__global__ __launch_bounds__(512, 2) void attn_kres3_kernel(AttnP p) {
-  constexpr int DH = 64, NDS = 4, NDT = 2, QB = 256;
-  constexpr int KREG = 768 * 128;
-  constexpr int VSLOT = 8192, VRING = KREG;
-  constexpr int WST = KREG + 4 * VSLOT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const bool lag = PHASED && wid >= 4;                    // wave-uniform: this wave's barriers sit one phase later
-
-  const int nqb = (p.Nq + QB - 1) / QB;
-  const int BH = p.B * p.H;
-  int bh, sp;
-  {
-    const int b = blockIdx.x;
-    if ((BH & 7) == 0) { const int xcd = b & 7, slot = b >> 3; bh = (slot / p.nsplit) * 8 + xcd; sp = slot % p.nsplit; }
-    else { bh = b / p.nsplit; sp = b % p.nsplit; }
-  }
-  const int qper = (nqb + p.nsplit - 1) / p.nsplit;
-  const int qb0 = sp * qper, qb1 = min(nqb, qb0 + qper);
-  if (qb0 >= qb1) return;
-  const int nkb = p.Nk >> 6;
-  const int ngrp = nkb >> 2;
-
-  const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
-  const char* Kg = reinterpret_cast<const char*>(p.K + (int64_t)bh * p.Nk_pad * DH);
-  const char* Vg = reinterpret_cast<const char*>(p.Vt + (int64_t)bh * DH * p.Nk_pad);
-  const int b_smp = bh / p.H, h_idx = bh - b_smp * p.H;
-
-  typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-  uint32_t fo[4], fk[4], fv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { fo[j] = lds0 + l31 * 128 + (((2 * j + hi) ^ ((l31 >> 1) & 7)) << 4); fk[j] = fo[j]; fv[j] = fo[j] + VRING; }
-  const int drow = 8 * wid + (lane >> 3), dchunk = ((lane & 7) ^ ((drow >> 1) & 7)) << 4;
-  const uint32_t koffs = drow * 128 + dchunk;
-  const uint32_t voffs = (uint32_t)drow * (uint32_t)p.Nk_pad * 2u + dchunk;
-  const char* kq = Kg; const char* vq = Vg;
-  int kb_k = 0, kb_v = 0;
-  auto issue_k = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs), (lds_void_t*)(smem + kb_k * 8192 + wid * 1024), 16, 0, 0);
-    ++kb_k; kq += 64 * DH * 2;
-  };
-  auto issue_v = [&]() __attribute__((always_inline)) {     // stage kb_v goes to ring slot kb_v & 3 (nkb is a multiple of 4)
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs), (lds_void_t*)(smem + VRING + (kb_v & 3) * VSLOT + wid * 1024), 16, 0, 0);
-    ++kb_v; vq += 64 * 2;
-    if (kb_v == nkb) { kb_v = 0; vq = Vg; }
-  };
-  bf16x8 qf[NDS];
-  auto dma_q = [&](int qb) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = j * 8 + (lane >> 3);
-      int qr = qb * QB + wid * 32 + row; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), (lds_void_t*)(smem + WST + wid * 4096 + j * 1024), 16, 0, 0);
-    }
-  };
-  auto scale_q = [&](uint32_t (&u)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      u[jj] = pack2bf(bf2f((bf16_t)(u[jj] & 0xffffu)) * p.scale_log2, bf2f((bf16_t)(u[jj] >> 16)) * p.scale_log2);
-  };
-  auto read_q = [&]() __attribute__((always_inline)) {
-    const uint32_t qrow = lds0 + WST + wid * 4096 + l31 * 128;
-#pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) {
-      union { uint32_t u[4]; bf16x8 v; } cv;
-      cv.v = *(lds_frag_t*)(uintptr_t)(qrow + (((2 * ds + hi) ^ ((l31 >> 1) & 7)) << 4));
-      scale_q(cv.u);
-      qf[ds] = cv.v;
-    }
-  };
-
-  f32x16 oacc[NDT], lacc, stA, stB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; lacc[r] = 0.f; }
-  bf16x8 ones;
-  { union { uint32_t u[4]; bf16x8 v; } cv; cv.u[0] = cv.u[1] = cv.u[2] = cv.u[3] = 0x3F803F80u; ones = cv.v; }
-  uint32_t ovf = 0;
-  bf16x8 kf[NDS], vf[2 * NDT], pb[2];
-
-  auto load_kf = [&](auto off_tag) __attribute__((always_inline)) {
-    constexpr int OFF = decltype(off_tag)::value;
-#pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) kf[ds] = *(lds_frag_t*)(uintptr_t)(fk[ds] + OFF);
-  };
-  auto load_vf = [&](auto slot_tag, auto kt_tag) __attribute__((always_inline)) {
-    constexpr int OFF = decltype(slot_tag)::value * VSLOT;
-    constexpr int KT = decltype(kt_tag)::value;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-        vf[s * NDT + dt] = *(lds_frag_t*)(uintptr_t)(fv[2 * KT + s] + OFF + dt * 4096);
-  };
-  auto store_o = [&](int qb, float inv) __attribute__((always_inline)) {
-    const int q0 = qb * QB + wid * 32;
-    uint32_t wbase = lds0 + WST + wid * 4096;
-    asm volatile("" : "+s"(wbase));
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-        const u32x2_t ov = {pack2bf(oacc[dt][4 * gq + 0] * inv, oacc[dt][4 * gq + 1] * inv), pack2bf(oacc[dt][4 * gq + 2] * inv, oacc[dt][4 * gq + 3] * inv)};
-        const int c8 = dt * 8 + 2 * gq + hi;
-        const uint32_t oaddr = wbase + l31 * 128 + ((c8 ^ (l31 & 15)) << 3);
-        asm volatile("ds_write_b64 %0, %1" :: "v"(oaddr), "v"(ov) : "memory");
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 8 * i + (lane >> 3), c16 = lane & 7;
-      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-      typedef __attribute__((address_space(3))) const u32x4_t lds_u4_t;
-      const u32x4_t vr = *(lds_u4_t*)(uintptr_t)(wbase + r * 128 + ((c16 ^ ((r & 15) >> 1)) << 4));
-      uint4 v = make_uint4(vr.x, vr.y, vr.z, vr.w);
-      if (r & 1) { const uint32_t t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
-      if (!(LN3D_KRES3_ABL & 64) || qb == 1000000) *reinterpret_cast<uint4*>(p.O + ((int64_t)b_smp * p.Nq + q0 + r) * p.ldo + h_idx * DH + c16 * 8) = v;
-    }
-  };
-  auto finish_block = [&](int qb) __attribute__((always_inline)) {
-    const float l = lacc[0];
-    if (__builtin_amdgcn_ballot_w64(!(l > 1.0e-30f && l < 1.0e30f)) != 0) ovf |= 1u << (qb - qb0);
-    store_o(qb, 1.0f / l);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; lacc[r] = 0.f; }
-  };
-
-#define SB3_ __builtin_amdgcn_sched_barrier(0)
-#define EXP3_(x_) ((LN3D_KRES3_ABL & 1) ? (x_) : __builtin_amdgcn_exp2f(x_))
-#define MFMA3_(a_, b_, c_) ((LN3D_KRES3_ABL & 2) ? abl_nomfma(a_, b_, c_) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0))
-  // V phase of a tile: its V^T columns and the K rows of the NEXT tile (`loads`), P = exp2(S) as bf16 pairs
-  auto phase_v = [&](const f32x16& cur, auto&& loads) __attribute__((always_inline)) {
-    if constexpr (!(LN3D_KRES3_ABL & 8)) loads();
-    SB3_;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      union { uint32_t u[4]; bf16x8 v; } cv;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) cv.u[jj] = pack2bf(EXP3_(cur[8 * s + 2 * jj]), EXP3_(cur[8 * s + 2 * jj + 1]));
-      pb[s] = cv.v;
-    }
-    SB3_;
-  };
-  // M phase: S^T of the next tile (kf) into nxt, PV + row sums of the current tile (vf, pb); 10 MFMAs back to back
-  auto phase_m = [&](f32x16& nxt, auto next_tag) __attribute__((always_inline)) {
-    const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    oacc[0] = MFMA3_(vf[0], pb[0], oacc[0]);
-    oacc[1] = MFMA3_(vf[1], pb[0], oacc[1]);
-    lacc = MFMA3_(ones, pb[0], lacc);
-    oacc[0] = MFMA3_(vf[2], pb[1], oacc[0]);
-    oacc[1] = MFMA3_(vf[3], pb[1], oacc[1]);
-    lacc = MFMA3_(ones, pb[1], lacc);
-    if constexpr (decltype(next_tag)::value) {
-      nxt = MFMA3_(kf[0], qf[0], zc);
-      nxt = MFMA3_(kf[1], qf[1], nxt);
-      nxt = MFMA3_(kf[2], qf[2], nxt);
-      nxt = MFMA3_(kf[3], qf[3], nxt);
-    }
-    SB3_;
-  };
-
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  using YES = std::true_type; using NO = std::false_type;
-  // ---- prologue: Q x4, K0, K1, K2, V0, K3, V1, K4, V2 (the order of the stream: step i issues K block i+5 and V^T stage i+3)
-  dma_q(qb0);
-  issue_k(); issue_k(); issue_k(); issue_v(); issue_k(); issue_v(); issue_k(); issue_v();
-  asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // queries + K0
-  __builtin_amdgcn_s_barrier();
-  read_q();
-  {
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    load_kf(I0{});
-#pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) stA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], ds == 0 ? z : stA, 0, 0, 0);
-  }
-
-  // top of step g of query block qb_: stage g (issued at step g-3) and K block g+1 (step g-4, first query block) have landed for
-  // every wave; behind the barrier the slot of step g-1 takes stage g+3.  W as in attn_kres_kernel, O stores not counted.
-  auto top = [&](int g, int qb_, bool with_q) __attribute__((always_inline)) {
-    const bool p1 = qb_ == qb0, lastgrp = g + 4 >= nkb, more = qb_ + 1 < qb1;
-    int w = p1 ? (lastgrp ? ((g & 3) == 0 ? 3 : 2) : 4) : 2;
-    if (g >= 1 && g <= 3 && more) w += 4;
-    if constexpr (!(LN3D_KRES3_ABL & 4)) {
-      switch (w) {
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    if constexpr (!(LN3D_KRES3_ABL & 16)) {
-      if (p1 && kb_k < nkb) issue_k();
-      issue_v();
-      if (with_q) dma_q(qb_ + 1);
-    }
-  };
-  auto advance_k = [&](bool wrap) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fk[j] = wrap ? fo[j] : fk[j] + 32768;
-  };
-  // step g = key block g: tile 0 (S in stA) then tile 1 (S in stB).  V_A reads K (g, 1); V_B reads K (g+1, 0).
-#define V_A(SL_) phase_v(stA, [&]() __attribute__((always_inline)) { load_kf(std::integral_constant<int, SL_ * 8192 + 4096>{}); load_vf(std::integral_constant<int, SL_>{}, I0{}); })
-#define V_B(SL_, KOFF_) phase_v(stB, [&]() __attribute__((always_inline)) { load_kf(std::integral_constant<int, KOFF_>{}); load_vf(std::integral_constant<int, SL_>{}, I1{}); })
-#define STEP3(SL_)                                                                      \
-  {                                                                                     \
-    if (!lag) top(g0 + SL_, qb, g0 + SL_ == 0 && more);                                  \
-    V_A(SL_); phase_m(stB, YES{}); V_B(SL_, (SL_ + 1) * 8192);                           \
-    if (lag) top(g0 + SL_ + 1, qb, false);                                               \
-    phase_m(stA, YES{});                                                                 \
-  }
-  if (lag) { top(0, qb0, false); if (qb0 + 1 < qb1) dma_q(qb0 + 1); }
-  for (int qb = qb0; qb < qb1; ++qb) {
-    const bool more = qb + 1 < qb1;
-    int g0 = 0;
-    for (int grp = 1; grp < ngrp; ++grp, g0 += 4) {
-      STEP3(0); STEP3(1); STEP3(2);
-      if (!lag) top(g0 + 3, qb, false);
-      V_A(3); phase_m(stB, YES{});
-      advance_k(false);
-      V_B(3, 0);
-      if (lag) top(g0 + 4, qb, false);
-      phase_m(stA, YES{});
-    }
-    STEP3(0); STEP3(1); STEP3(2);
-    if (!lag) top(g0 + 3, qb, false);
-    V_A(3); phase_m(stB, YES{});
-    advance_k(true);
-    if (more) {
-      V_B(3, 0);                                          // K block 0 again: the next tile opens the next query block
-      read_q();
-      if (lag) top(0, qb + 1, false);
-      phase_m(stA, YES{});
-      finish_block(qb);
-      if (lag && qb + 2 < qb1) dma_q(qb + 2);            // behind the O staging of this block (same 4 KB)
-    } else {
-      phase_v(stB, [&]() __attribute__((always_inline)) { load_vf(I3{}, I1{}); });
-      phase_m(stA, NO{});
-      finish_block(qb);
-    }
-  }
-#undef STEP3
-#undef V_A
-#undef V_B
-#undef SB3_
-#undef EXP3_
-#undef MFMA3_
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-
-  // ---- exact recomputation of flagged query blocks (rare)
-  if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + WST + wid * 4096) = ovf;
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-  uint32_t redo = 0;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) redo |= *reinterpret_cast<volatile uint32_t*>(smem + WST + w * 4096);
-  redo = __builtin_amdgcn_readfirstlane(redo);
-  if constexpr (LN3D_KRES3_ABL != 0) redo = 0;
-  while (redo) {
-    const int blk = __builtin_ctz(redo);
-    redo &= redo - 1;
-    const int qb = qb0 + blk;
-    {
-      int qr = qb * QB + wid * 32 + l31; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-#pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        union { uint32_t u[4]; uint4 q; bf16x8 v; } cv;
-        cv.q = *reinterpret_cast<const uint4*>(Qg + (int64_t)qr * DH + (2 * ds + hi) * 8);
-        scale_q(cv.u);
-        qf[ds] = cv.v;
-      }
-    }
-    float m_run = -3.0e38f, l_run = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-    for (int kb = 0; kb < nkb; ++kb) {
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Vg + kb * 128 + voffs), (lds_void_t*)(smem + VRING + wid * 1024), 16, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      f32x16 st[2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < NDS; ++ds)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          const bf16x8 kfr = *(lds_frag_t*)(uintptr_t)(fo[ds] + kb * 8192 + kt * 4096);
-          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ds], st[kt], 0, 0, 0);
-        }
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_run); st[kt][r] = pv; psum += pv; }
-      l_run += psum;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        union { uint32_t u[4]; bf16x8 v; } cv;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          cv.u[jj] = pack2bf(st[s >> 1][8 * (s & 1) + 2 * jj], st[s >> 1][8 * (s & 1) + 2 * jj + 1]);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          const bf16x8 vfr = *(lds_frag_t*)(uintptr_t)(fv[s] + dt * 4096);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, cv.v, oacc[dt], 0, 0, 0);
-        }
-      }
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    store_o(qb, 1.0f / l_tot);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K-resident kernel, one wave per SIMD (r3, second form): a workgroup is 4 waves x 64 queries (two 32-query tiles a / b per
-// wave) with the whole 512-entry register file per wave.  What the r3 ablations of attn_kres_kernel showed
-// (profiles/r3_attn.md): with 8 lock-stepped waves x 32 queries every cost is ADDITIVE - MFMA 23 us + fragment reads 12 + exp 4
-// + sync 3 + rest 8 = 50 us - because all waves hit the LDS, then the VALU, then the matrix pipe at the same time and an
-// in-order wave cannot overlap its own phases.  Here the overlap is built into ONE wave's instruction stream instead:
-//  * a K / V^T fragment read feeds two MFMAs (tiles a and b): half the LDS traffic per MFMA;
-//  * 20 MFMAs per 32-key tile (8 S^T, 8 PV, 4 row-sum) in an order where MFMAs on the same accumulator are >= 2 apart, and
-//    between consecutive MFMAs sit ~3 of the 48 exp / pack instructions or of the 8 fragment reads (V^T of this tile during
-//    its S^T phase, K of the next tile during its last PV phase): no fragment double-buffering, no exposed LDS latency;
-//  * no softmax reference at all: P = exp2(s * scale * log2 e) as it is (floating point is scale-free; |s| would have to
-//    exceed 2^7 for P or the sums to leave the fp32 / bf16 range).  A row whose sum is not inside (1e-30, 1e30) flags its
-//    query block, which is then recomputed by the exact online-softmax loop at the end of the workgroup.
-//  K stays resident (<= 96 KB), V^T streams through 4 slots x 64 keys, queries arrive by LDS-DMA one block ahead.
-#ifndef LN3D_KRES2_ABL   // tools/attn_bench.hip only: 1 no v_exp, 2 no MFMA, 4 no barrier / DMA wait, 8 no fragment reads, 32 hipcc's order
-#define LN3D_KRES2_ABL 0
-#endif
-template <bool ST_INORDER>
-__global__ __launch_bounds__(256, 2) void attn_kres2_kernel(AttnP p) {   // 2 = register cap 256: everything in arch VGPRs (see half_step)
-  constexpr int DH = 64, NDS = 4, QB = 256;
-  constexpr int KREG = 768 * 128;                         // resident K rows (128 B each)
-  constexpr int VSLOT = 8192, VRING = KREG;               // V^T ring: 4 slots x (64 dims x 64 keys)
-  constexpr int WST = KREG + 4 * VSLOT;                   // 4 x 8 KB: per-wave staging (64 query rows in by LDS-DMA, O out)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-
-  const int nqb = (p.Nq + QB - 1) / QB;
-  const int BH = p.B * p.H;
-  int bh, sp;
-  {
-    const int b = blockIdx.x;
-    if ((BH & 7) == 0) { const int xcd = b & 7, slot = b >> 3; bh = (slot / p.nsplit) * 8 + xcd; sp = slot % p.nsplit; }
-    else { bh = b / p.nsplit; sp = b % p.nsplit; }
-  }
-  const int qper = (nqb + p.nsplit - 1) / p.nsplit;
-  const int qb0 = sp * qper, qb1 = min(nqb, qb0 + qper);
-  if (qb0 >= qb1) return;
-  const int nkb = p.Nk >> 6;                              // 8 or 12 key blocks of 64 (launcher)
-  const int ngrp = nkb >> 2;
-
-  const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
-  const char* Kg = reinterpret_cast<const char*>(p.K + (int64_t)bh * p.Nk_pad * DH);
-  const char* Vg = reinterpret_cast<const char*>(p.Vt + (int64_t)bh * DH * p.Nk_pad);
-  const int b_smp = bh / p.H, h_idx = bh - b_smp * p.H;
-
-  typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-  uint32_t fo[4], fk[4], fv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { fo[j] = lds0 + l31 * 128 + (((2 * j + hi) ^ ((l31 >> 1) & 7)) << 4); fk[j] = fo[j]; fv[j] = fo[j] + VRING; }
-  // DMA pieces (1 KB = 8 rows x 128 B): wave w fills pieces 2w and 2w+1 of a K block / of a V^T stage
-  const int drow0 = 16 * wid + (lane >> 3), drow1 = drow0 + 8;
-  const uint32_t dch0 = ((lane & 7) ^ ((drow0 >> 1) & 7)) << 4, dch1 = ((lane & 7) ^ ((drow1 >> 1) & 7)) << 4;
-  const uint32_t koffs0 = drow0 * 128 + dch0, koffs1 = drow1 * 128 + dch1;
-  const uint32_t voffs0 = (uint32_t)drow0 * (uint32_t)p.Nk_pad * 2u + dch0, voffs1 = (uint32_t)drow1 * (uint32_t)p.Nk_pad * 2u + dch1;
-  const char* kq = Kg; const char* vq = Vg;
-  int kb_k = 0, kb_v = 0;
-  auto issue_k = [&]() __attribute__((always_inline)) {
-    char* dst = smem + kb_k * 8192 + wid * 2048;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs0), (lds_void_t*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs1), (lds_void_t*)(dst + 1024), 16, 0, 0);
-    ++kb_k; kq += 64 * DH * 2;
-  };
-  auto issue_v = [&](auto slot_tag) __attribute__((always_inline)) {
-    constexpr int SL = decltype(slot_tag)::value & 3;
-    char* dst = smem + VRING + SL * VSLOT + wid * 2048;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs0), (lds_void_t*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs1), (lds_void_t*)(dst + 1024), 16, 0, 0);
-    ++kb_v; vq += 64 * 2;
-    if (kb_v == nkb) { kb_v = 0; vq = Vg; }
-  };
-  char* const wstage = smem + WST + wid * 8192;           // rows 0-31: query tile a, rows 32-63: tile b (4 KB each)
-  auto dma_q = [&](int qb) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int row = j * 8 + (lane >> 3);
-      int qr = qb * QB + wid * 64 + row; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), (lds_void_t*)(wstage + j * 1024), 16, 0, 0);
-    }
-  };
-  auto scale_q = [&](uint32_t (&u)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      u[jj] = pack2bf(bf2f((bf16_t)(u[jj] & 0xffffu)) * p.scale_log2, bf2f((bf16_t)(u[jj] >> 16)) * p.scale_log2);
-  };
-  bf16x8 qf[2][NDS];
-  auto read_q = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t qrow = lds0 + WST + wid * 8192 + t * 4096 + l31 * 128;
-#pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        union { uint32_t u[4]; bf16x8 v; } cv;
-        cv.v = *(lds_frag_t*)(uintptr_t)(qrow + (((2 * ds + hi) ^ ((l31 >> 1) & 7)) << 4));
-        scale_q(cv.u);
-        qf[t][ds] = cv.v;
-      }
-    }
-  };
-
-  f32x16 oacc[2][2], lacc[2], st[2];                     // [query tile][...]
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[t][0][r] = 0.f; oacc[t][1][r] = 0.f; lacc[t][r] = 0.f; }
-  bf16x8 ones;
-  { union { uint32_t u[4]; bf16x8 v; } cv; cv.u[0] = cv.u[1] = cv.u[2] = cv.u[3] = 0x3F803F80u; ones = cv.v; }
-  uint32_t ovf = 0;
-
-  bf16x8 kf[NDS], vf[4];
-  auto load_kf = [&](auto off_tag, auto lo_tag, auto n_tag) __attribute__((always_inline)) {      // K rows at fk + OFF: fragments LO .. LO+N-1
-    constexpr int OFF = decltype(off_tag)::value, LO = decltype(lo_tag)::value, N = decltype(n_tag)::value;
-#pragma unroll
-    for (int ds = LO; ds < LO + N; ++ds) kf[ds] = *(lds_frag_t*)(uintptr_t)(fk[ds] + OFF);
-  };
-  auto load_vf = [&](auto slot_tag, auto kt_tag, auto lo_tag, auto n_tag) __attribute__((always_inline)) {
-    constexpr int OFF = decltype(slot_tag)::value * VSLOT, KT = decltype(kt_tag)::value, LO = decltype(lo_tag)::value, N = decltype(n_tag)::value;
-#pragma unroll
-    for (int i = LO; i < LO + N; ++i)                      // i = 2 s + dt
-      vf[i] = *(lds_frag_t*)(uintptr_t)(fv[2 * KT + (i >> 1)] + OFF + (i & 1) * 4096);
-  };
-  auto store_o = [&](int qb, int t, float inv) __attribute__((always_inline)) {
-    const int q0 = qb * QB + wid * 64 + t * 32;
-    uint32_t wbase = lds0 + WST + wid * 8192 + t * 4096;
-    asm volatile("" : "+s"(wbase));                       // opaque LDS address (see attn_kres_kernel::store_o)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-        const u32x2_t ov = {pack2bf(oacc[t][dt][4 * gq + 0] * inv, oacc[t][dt][4 * gq + 1] * inv),
-                            pack2bf(oacc[t][dt][4 * gq + 2] * inv, oacc[t][dt][4 * gq + 3] * inv)};
-        const int c8 = dt * 8 + 2 * gq + hi;
-        const uint32_t oaddr = wbase + l31 * 128 + ((c8 ^ (l31 & 15)) << 3);
-        asm volatile("ds_write_b64 %0, %1" :: "v"(oaddr), "v"(ov) : "memory");
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 8 * i + (lane >> 3), c16 = lane & 7;
-      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-      typedef __attribute__((address_space(3))) const u32x4_t lds_u4_t;
-      const u32x4_t vr = *(lds_u4_t*)(uintptr_t)(wbase + r * 128 + ((c16 ^ ((r & 15) >> 1)) << 4));
-      uint4 v = make_uint4(vr.x, vr.y, vr.z, vr.w);
-      if (r & 1) { const uint32_t t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
-      *reinterpret_cast<uint4*>(p.O + ((int64_t)b_smp * p.Nq + q0 + r) * p.ldo + h_idx * DH + c16 * 8) = v;
-    }
-  };
-  auto finish_block = [&](int qb) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float l = lacc[t][0];
-      if (__builtin_amdgcn_ballot_w64(!(l > 1.0e-30f && l < 1.0e30f)) != 0) ovf |= 1u << (qb - qb0);
-      store_o(qb, t, 1.0f / l);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[t][0][r] = 0.f; oacc[t][1][r] = 0.f; lacc[t][r] = 0.f; }
-    }
-  };
-
-#define SB2_ do { if constexpr (!(LN3D_KRES2_ABL & 32)) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define EXP2_(x_) ((LN3D_KRES2_ABL & 1) ? (x_) : __builtin_amdgcn_exp2f(x_))
-#define MFMA2_(a_, b_, c_) ((LN3D_KRES2_ABL & 2) ? abl_nomfma(a_, b_, c_) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0))
-  // One half-step = one 32-key tile, both query tiles:
-  //   12 VALU      : exp + pack of keys 0-15 of tile a (under the tail of the previous half-step's S^T MFMAs)
-  //   12 MFMAs     : PV + row sums, keys 0-15 then 16-31, a then b | the other 36 exp / pack instructions, 4 K fragment reads
-  //    8 MFMAs     : S^T of the NEXT key tile (a, b alternating: the same accumulator every second MFMA) | 4 V^T fragment reads
-  // S lives in ONE register set per query tile: its last exp is issued before the first S^T MFMA of the next tile overwrites
-  // it.  With a second set (S^T first, as in attn_kres_kernel) the kernel needs > 256 registers, hipcc then moves EVERY MFMA
-  // result to AGPRs and copies each S tile back with 16 v_accvgpr_read behind an s_nop 11.
-  // kf: K rows of the next tile (read here, late in the PV phase); vf[0..1]: V^T columns of keys 0-15 of this tile (read during the
-  // previous S^T phase), vf[2..3]: keys 16-31 (read here, under the first PV MFMAs) - short live ranges, the kernel sits at the
-  // 256-register cap.  loads_vc: V^T of the current tile, loads_v: of the next.  MODE 0: normal ; 3: nothing follows.
-  auto half_step = [&](auto mode_tag, auto&& loads_k, auto&& loads_vc, auto&& loads_v) __attribute__((always_inline)) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t pk[2][2][4];                                  // [tile][16-key half][4 dwords]: P as bf16 pairs = the PV B operand
-    auto pbv = [&](int t, int s_) __attribute__((always_inline)) { union { uint32_t u[4]; bf16x8 v; } cv; _Pragma("unroll") for (int j = 0; j < 4; ++j) cv.u[j] = pk[t][s_][j]; return cv.v; };
-#define PEXP_(t_, s_, j_) { const float e0_ = EXP2_(st[t_][8 * (s_) + 2 * (j_)]), e1_ = EXP2_(st[t_][8 * (s_) + 2 * (j_) + 1]); pk[t_][s_][j_] = pack2bf(e0_, e1_); }
-#define LK_(i_) { if constexpr (MODE != 3 && !(LN3D_KRES2_ABL & 8)) loads_k(std::integral_constant<int, i_>{}); }
-#define LV2_(i_) { if constexpr (MODE != 3 && !(LN3D_KRES2_ABL & 8)) loads_v(std::integral_constant<int, i_>{}); }
-#define LVC_(i_) { if constexpr (!(LN3D_KRES2_ABL & 8)) loads_vc(std::integral_constant<int, i_>{}); }
-    PEXP_(0, 0, 0); PEXP_(0, 0, 1); PEXP_(0, 0, 2); PEXP_(0, 0, 3); SB2_;
-    oacc[0][0] = MFMA2_(vf[0], pbv(0, 0), oacc[0][0]); SB2_;
-    PEXP_(1, 0, 0); PEXP_(1, 0, 1); LVC_(2); SB2_;
-    oacc[0][1] = MFMA2_(vf[1], pbv(0, 0), oacc[0][1]); SB2_;
-    PEXP_(1, 0, 2); LVC_(3); SB2_;
-    lacc[0] = MFMA2_(ones, pbv(0, 0), lacc[0]); SB2_;
-    PEXP_(1, 0, 3); SB2_;
-    oacc[1][0] = MFMA2_(vf[0], pbv(1, 0), oacc[1][0]); SB2_;
-    PEXP_(0, 1, 0); PEXP_(0, 1, 1); SB2_;
-    oacc[1][1] = MFMA2_(vf[1], pbv(1, 0), oacc[1][1]); SB2_;
-    PEXP_(0, 1, 2); SB2_;
-    lacc[1] = MFMA2_(ones, pbv(1, 0), lacc[1]); SB2_;
-    PEXP_(0, 1, 3); SB2_;
-    oacc[0][0] = MFMA2_(vf[2], pbv(0, 1), oacc[0][0]); SB2_;
-    PEXP_(1, 1, 0); PEXP_(1, 1, 1); SB2_;
-    oacc[0][1] = MFMA2_(vf[3], pbv(0, 1), oacc[0][1]); SB2_;
-    PEXP_(1, 1, 2); LK_(0); SB2_;
-    lacc[0] = MFMA2_(ones, pbv(0, 1), lacc[0]); SB2_;
-    PEXP_(1, 1, 3); LK_(1); SB2_;
-    oacc[1][0] = MFMA2_(vf[2], pbv(1, 1), oacc[1][0]); SB2_;
-    LK_(2); SB2_;
-    oacc[1][1] = MFMA2_(vf[3], pbv(1, 1), oacc[1][1]); SB2_;
-    LK_(3); SB2_;
-    lacc[1] = MFMA2_(ones, pbv(1, 1), lacc[1]); SB2_;
-    if constexpr (MODE != 3) {
-      st[0] = MFMA2_(kf[0], qf[0][0], zc);
-      st[1] = MFMA2_(kf[0], qf[1][0], zc); SB2_;
-      st[0] = MFMA2_(kf[1], qf[0][1], st[0]);
-      st[1] = MFMA2_(kf[1], qf[1][1], st[1]); SB2_;
-      LV2_(0); SB2_;
-      st[0] = MFMA2_(kf[2], qf[0][2], st[0]);
-      st[1] = MFMA2_(kf[2], qf[1][2], st[1]); SB2_;
-      LV2_(1); SB2_;
-      st[0] = MFMA2_(kf[3], qf[0][3], st[0]);
-      st[1] = MFMA2_(kf[3], qf[1][3], st[1]); SB2_;
-    }
-#undef PEXP_
-#undef LK_
-#undef LV2_
-#undef LVC_
-  };
-
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  // ---- prologue.  Issue order = the order of the stream below (step i issues K block i+5 and V^T stage i+3; 2 requests each):
-  //      Q x8, K0, K1, K2, V0, K3, V1, K4, V2.  The first tile needs the queries, K0 and V0: 8 younger requests.
-  dma_q(qb0);
-  issue_k(); issue_k(); issue_k(); issue_v(I0{}); issue_k(); issue_v(I1{}); issue_k(); issue_v(I2{});
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  read_q();
-  {
-    load_kf(I0{}, I0{}, std::integral_constant<int, 4>{});
-    load_vf(I0{}, I0{}, I0{}, std::integral_constant<int, 2>{});
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[t][ds], ds == 0 ? z : st[t], 0, 0, 0);
-  }
-
-  // ---- the stream.  Step g (V^T ring slot SL = g & 3) = half-step A: PV of tile (g, 0), S^T of tile (g, 1), reads K (g, 1) and
-  // V^T (g, 1); half-step B: PV of tile (g, 1), S^T of tile (g+1, 0), reads K (g+1, 0) and V^T (g+1, 0).  At the top of step g, V^T
-  // stage g+1 (issued during step g-2) and K block g+1 (step g-4, first query block only) must have landed for every wave; behind
-  // the barrier every wave has left step g-1, whose ring slot takes stage g+3.  W = requests (2 per wave and block) issued behind
-  // stage g+1:
-  //   later query blocks: V(g+2)                           -> 2
-  //   first query block : K(g+4), V(g+2) while K(g+4) exists -> 4 ; 2 in its last group
-  //   + 8 while the next block's query DMA (issued in step 0, behind that step's pair) is younger  : steps 1, 2 of a block
-  //   + 8 while the previous block's O stores (end of its last step) are younger                   : steps 0, 1 of a later block
-  auto wait_w = [&](int w) __attribute__((always_inline)) {
-    switch (w) {
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
-  auto top_of_step = [&](auto slot_tag, bool first, bool lastgrp, bool p1, bool more, bool stq, int qb) __attribute__((always_inline)) {
-    constexpr int SL = decltype(slot_tag)::value;
-    int w = (p1 && !lastgrp) ? 4 : 2;
-    if (first && more && (SL == 1 || SL == 2)) w += 8;
-    if (ST_INORDER && first && stq && SL <= 1) w += 8;
-    if constexpr (!(LN3D_KRES2_ABL & 4)) { wait_w(w); __builtin_amdgcn_s_barrier(); }
-    if (p1 && kb_k < nkb) issue_k();
-    issue_v(std::integral_constant<int, SL + 3>{});
-    if (SL == 0 && first && more) dma_q(qb + 1);
-  };
-  auto advance_k = [&](bool wrap) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fk[j] = wrap ? fo[j] : fk[j] + 32768;
-  };
-#define LKF_(OFF_) [&](auto i_) __attribute__((always_inline)) { load_kf(std::integral_constant<int, OFF_>{}, i_, I1{}); }
-#define LVF_(SL_, KT_) [&](auto i_) __attribute__((always_inline)) { load_vf(std::integral_constant<int, (SL_) & 3>{}, std::integral_constant<int, KT_>{}, i_, I1{}); }
-#define NONE_ [&](auto) __attribute__((always_inline)) {}
-  // A: next tile = (g, 1) ; B: next tile = (g+1, 0), K at KOFF_ relative to fk, V^T in slot SL+1
-#define HS2_A(SL_) half_step(I0{}, LKF_((SL_) * 8192 + 4096), LVF_(SL_, 0), LVF_(SL_, 1))
-#define HS2_B(SL_, KOFF_) half_step(I0{}, LKF_(KOFF_), LVF_(SL_, 1), LVF_((SL_) + 1, 0))
-#define STEP2(SL_, LASTG_) { top_of_step(std::integral_constant<int, SL_>{}, first, LASTG_, p1, more, stq, qb); HS2_A(SL_); HS2_B(SL_, ((SL_) + 1) * 8192); }
-  for (int qb = qb0; qb < qb1; ++qb) {
-    const bool more = qb + 1 < qb1, p1 = qb == qb0, stq = qb != qb0;
-    bool first = true;
-    for (int grp = 1; grp < ngrp; ++grp) {
-      STEP2(0, false); STEP2(1, false); STEP2(2, false);
-      top_of_step(I3{}, first, false, p1, more, stq, qb);
-      HS2_A(3);
-      HS2_B(3, 32768);                                    // K block g+1 = block 0 of the next group
-      advance_k(false);
-      first = false;
-    }
-    STEP2(0, true); STEP2(1, true); STEP2(2, true);
-    top_of_step(I3{}, first, true, p1, more, stq, qb);
-    HS2_A(3);
-    advance_k(true);
-    if (more) {
-      read_q();                                           // the next S^T tile opens the next query block: its queries, K block 0
-      HS2_B(3, 0);
-    } else {
-      half_step(I3{}, NONE_, LVF_(3, 1), NONE_);
-    }
-    finish_block(qb);
-  }
-#undef STEP2
-#undef HS2_A
-#undef HS2_B
-#undef LKF_
-#undef LVF_
-#undef NONE_
-#undef SB2_
-#undef EXP2_
-#undef MFMA2_
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-
-  // ---- exact recomputation of flagged query blocks (rare): plain online softmax, one 32-query tile at a time
-  if (lane == 0) *reinterpret_cast<volatile uint32_t*>(wstage) = ovf;
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-  uint32_t redo = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) redo |= *reinterpret_cast<volatile uint32_t*>(smem + WST + w * 8192);
-  redo = __builtin_amdgcn_readfirstlane(redo);
-  if constexpr (LN3D_KRES2_ABL != 0) redo = 0;
-  while (redo) {
-    const int blk = __builtin_ctz(redo);
-    redo &= redo - 1;
-    const int qb = qb0 + blk;
-    for (int t = 0; t < 2; ++t) {
-      bf16x8 qx[NDS];
-      {
-        int qr = qb * QB + wid * 64 + t * 32 + l31; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-          union { uint32_t u[4]; uint4 q; bf16x8 v; } cv;
-          cv.q = *reinterpret_cast<const uint4*>(Qg + (int64_t)qr * DH + (2 * ds + hi) * 8);
-          scale_q(cv.u);
-          qx[ds] = cv.v;
-        }
-      }
-      float m_run = -3.0e38f, l_run = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][0][r] = 0.f; oacc[0][1][r] = 0.f; }
-      for (int kb = 0; kb < nkb; ++kb) {
-        __builtin_amdgcn_s_barrier();                     // ring slot 0 is free
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(Vg + kb * 128 + voffs0), (lds_void_t*)(smem + VRING + wid * 2048), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(Vg + kb * 128 + voffs1), (lds_void_t*)(smem + VRING + wid * 2048 + 1024), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        f32x16 st[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds)
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const bf16x8 kfr = *(lds_frag_t*)(uintptr_t)(fo[ds] + kb * 8192 + kt * 4096);
-            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qx[ds], st[kt], 0, 0, 0);
-          }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][0][r] *= alpha; oacc[0][1][r] *= alpha; }
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { const float pv = __builtin_amdgcn_exp2f(st[kt][r] - m_run); st[kt][r] = pv; psum += pv; }
-        l_run += psum;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          union { uint32_t u[4]; bf16x8 v; } cv;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            cv.u[jj] = pack2bf(st[s >> 1][8 * (s & 1) + 2 * jj], st[s >> 1][8 * (s & 1) + 2 * jj + 1]);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vfr = *(lds_frag_t*)(uintptr_t)(fv[s] + dt * 4096);
-            oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, cv.v, oacc[0][dt], 0, 0, 0);
-          }
-        }
-      }
-      const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-      // store_o reads oacc[t]: move the result there
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float a0 = oacc[0][0][r], a1 = oacc[0][1][r]; oacc[t][0][r] = a0; oacc[t][1][r] = a1; }
-      store_o(qb, t, 1.0f / l_tot);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Short key sequences (Nk <= 128: the 77-token text context of every cross-attention, the CLIP text tower), Dh = 64.
 // The general kernel above is latency-bound there (ring prologue, a barrier per block, 768 workgroups on 512 slots).  Here a
 // workgroup is 4 waves = 256 queries of one (batch, head), every wave takes two 32-query tiles in turn; K and V^T of the whole
@@ -1982,17 +1230,17 @@ __global__ __launch_bounds__(256, 3) void attn_short_kernel(AttnP p) {
 
 // Measurement switches (environment, read ONCE per process; every setting runs HIP kernels of this file):
 //   LN3D_ATTN_V     2 = attn_kernel (r1 ring) for every shape, 3 = attn_stream_kernel where it applies, 4 / unset = default choice
-//   LN3D_ATTN_KRES  bit 0: static priority for waves 4-7, bit 1: count the O stores in the vmcnt waits, bit 2: attn_kres2_kernel
+//   LN3D_ATTN_KRES  bit 0: static priority for waves 4-7, bit 1: count the O stores in the vmcnt waits (default 1)
 //   LN3D_ATTN_SHORT 1 = short-sequence kernel for non-causal Nk <= 128 too;  LN3D_ATTN_QT 2 = two query tiles per wave there
 //   LN3D_ATTN_SPLIT workgroups per (batch, head) of the streaming kernels
 struct AttnCfg { int ver, kres, force_short, qt, split; };
-static AttnCfg g_attn_cfg = {-1, 3, 0, 1, 0};
+static AttnCfg g_attn_cfg = {-1, 1, 0, 1, 0};
 static const AttnCfg& attn_cfg() {
   if (g_attn_cfg.ver < 0) {
     const char* e;
-    AttnCfg c = {0, 3, 0, 1, 0};
+    AttnCfg c = {0, 1, 0, 1, 0};
     if ((e = getenv("LN3D_ATTN_V")) != nullptr) c.ver = atoi(e);
-    if ((e = getenv("LN3D_ATTN_KRES")) != nullptr) c.kres = atoi(e) & 15;
+    if ((e = getenv("LN3D_ATTN_KRES")) != nullptr) c.kres = atoi(e) & 3;
     if ((e = getenv("LN3D_ATTN_SHORT")) != nullptr) c.force_short = e[0] == '1';
     if ((e = getenv("LN3D_ATTN_QT")) != nullptr) c.qt = e[0] == '2' ? 2 : 1;
     if ((e = getenv("LN3D_ATTN_SPLIT")) != nullptr) c.split = atoi(e);
@@ -2068,32 +1316,8 @@ static int launch_attn_kres_t(const AttnP& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_kres_kernel<PRIO, ST_INORDER>), dim3(p.B * p.H * p.nsplit), dim3(512), LDS, s, p);
   return ln3d_check_launch();
 }
-template <bool ST_INORDER>
-static int launch_attn_kres2_t(const AttnP& p, hipStream_t s) {
-  constexpr int LDS = 768 * 128 + 4 * 8192 + 4 * 8192;   // all 160 KiB of the CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kres2_kernel<ST_INORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((attn_kres2_kernel<ST_INORDER>), dim3(p.B * p.H * p.nsplit), dim3(256), LDS, s, p);
-  return ln3d_check_launch();
-}
-template <bool PHASED>
-static int launch_attn_kres3_t(const AttnP& p, hipStream_t s) {
-  constexpr int LDS = 768 * 128 + 4 * 8192 + 8 * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kres3_kernel<PHASED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((attn_kres3_kernel<PHASED>), dim3(p.B * p.H * p.nsplit), dim3(512), LDS, s, p);
-  return ln3d_check_launch();
-}
 static int launch_attn_kres(AttnP p, hipStream_t s) {
   p.nsplit = 1;                                            // every workgroup walks all query blocks of its head: K is fetched once
-  if (attn_cfg().kres & 8) return (attn_cfg().kres & 1) ? launch_attn_kres3_t<true>(p, s) : launch_attn_kres3_t<false>(p, s);
-  if (attn_cfg().kres & 4) return (attn_cfg().kres & 2) ? launch_attn_kres2_t<true>(p, s) : launch_attn_kres2_t<false>(p, s);
   switch (attn_cfg().kres) {
     case 0: return launch_attn_kres_t<false, false>(p, s);
     case 1: return launch_attn_kres_t<true, false>(p, s);

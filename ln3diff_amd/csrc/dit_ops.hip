@@ -668,22 +668,30 @@ extern "C" int ln3d_lincomb(const float* y, const float* const* ks, const float*
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, p, out, n);
   return ln3d_check_launch();
 }
-__global__ void err_ratio_sq_kernel(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// sum_i (err_i / (atol + rtol max(|y0_i|, |y1_i|)))^2 -> acc[0].  ONE workgroup, fixed summation order: the accept / reject decision
+// of the adaptive ODE solver reads this number, so it must not depend on the arrival order of atomics (r2 used atomicAdd).
+__global__ __launch_bounds__(1024) void err_ratio_sq_kernel(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc, int64_t n) {
+  __shared__ float part[16];
   float v = 0.f;
-  if (i < n) {
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
     const float tol = atol + rtol * fmaxf(fabsf(y0[i]), y1 ? fabsf(y1[i]) : 0.f);
     const float r = err[i] / tol;
-    v = r * r;
+    v += r * r;
   }
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w];
+    acc[0] = t;
+  }
 }
 extern "C" int ln3d_err_ratio_sq(const float* err, const float* y0, const float* y1, float atol, float rtol, float* acc,
                                  int64_t n, void* stream) {
   if (!err || !y0 || !acc || n <= 0) return LN3D_ERR_BAD_ARG;
-  if (hipMemsetAsync(acc, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return LN3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(err_ratio_sq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, err, y0, y1, atol, rtol, acc, n);
+  hipLaunchKernelGGL(err_ratio_sq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, err, y0, y1, atol, rtol, acc, n);
   return ln3d_check_launch();
 }
 

@@ -30,6 +30,25 @@ _IGNORED_DEFAULTS = dict(lr=5e-5, batch_size=1, microbatch=-1, ema_rate='0.9999'
                          use_train_trajectory=False, cond_key='caption', use_eos_feature=False, interval=1, eval_batch_size=1)
 
 
+# Flags of the released launchers that describe the MODEL or the PREDICTION TYPE: accepted with the values those launchers pass, and
+# refused (with the reason) when set to something this build does not implement - silently dropping them would change what is
+# sampled.  (name: (default, {allowed values} or None = any, engines it matters for, message))
+_RELEASED_DECODER = 'vit.vit_triplane.RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder'
+_CHECKED = {
+    'mixed_prediction': (False, {False}, ('edm', 'flow', 'gd'), "the mixing-component denoiser output (LSGM mixed prediction) is not built"),
+    'predict_v': (False, None, ('gd',), None),            # see validate(): only the guided_diffusion engines read them
+    'pred_type': ('eps', None, ('gd',), None),            # (guided_diffusion/script_util.py:36-37,84,682-686: predict_v -> ModelMeanType.V)
+    'ae_classname': (_RELEASED_DECODER, {_RELEASED_DECODER}, ('edm', 'flow', 'gd'), "only the released decoder class is built"),
+    'vae_p': (2, {2}, ('edm', 'flow', 'gd'), "the decoder tokeniser is built for vae_p = 2"),
+    'denoise_out_channels': (4, None, ('edm', 'flow', 'gd'), None),
+    'decoder_in_chans': (32, {32}, ('edm', 'flow', 'gd'), "tri-plane feature width 32 (OSGDecoder 32 -> 64 -> 4)"),
+    'triplane_in_chans': (32, {32}, ('edm', 'flow', 'gd'), "tri-plane feature width 32"),
+    'out_chans': (96, {96}, ('edm', 'flow', 'gd'), "3 planes x 32 channels"),
+    'decoder_output_dim': (3, {3}, ('edm', 'flow', 'gd'), "RGB output"),
+    'patch_size': (14, None, (), None),                   # the VAE *encoder's* ViT patch size (DINO 14): encoder only, unused here
+}
+
+
 def str2bool(v):
     if isinstance(v, bool):
         return v
@@ -59,6 +78,7 @@ def create_argparser(objaverse=True):
         mv_input=False, num_mv_views=4, clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
         overwrite_diff_inp_size='', create_controlnet=False)
     d.update(_IGNORED_DEFAULTS)
+    d.update({k: v[0] for k, v in _CHECKED.items()})
     ap = argparse.ArgumentParser(allow_abbrev=False)
     add_dict_to_argparser(ap, d)
     return ap
@@ -100,6 +120,23 @@ def validate(args):
         args.mv_input = True
     if args.num_samples < 1 or args.num_views < 1:
         raise SystemExit("--num_samples and --num_views must be >= 1")
+    for name, (default, allowed, kinds, why) in _CHECKED.items():
+        val = getattr(args, name)
+        if allowed is not None and kind in kinds and val not in allowed:
+            raise SystemExit(f"--{name} {val}: {why} (supported: {sorted(allowed, key=str)})")
+    if args.denoise_out_channels != args.denoise_in_channels:
+        raise SystemExit(f"--denoise_out_channels {args.denoise_out_channels} != --denoise_in_channels {args.denoise_in_channels}: the "
+                         "samplers update the latent in place with the network output (learn_sigma False)")
+    if kind == 'gd' and (args.predict_v or args.pred_type not in ('eps', 'epsilon')):
+        # create_gaussian_diffusion maps --predict_v to ModelMeanType.V (guided_diffusion/script_util.py:682-686); the guided_diffusion
+        # engines of this build implement ModelMeanType.EPSILON.  (The released Objaverse launchers pass --predict_v True --pred_type v
+        # but run the sgm / flow-matching engines, which never read them - accepted there.)
+        raise SystemExit(f"--predict_v {args.predict_v} --pred_type {args.pred_type} with --trainer_name {args.trainer_name}: the "
+                         "guided_diffusion engines of this build predict epsilon only (ModelMeanType.V / START_X are not built)")
+    if 'PCD' in args.dit_model_arch:
+        raise SystemExit(f"--dit_model_arch {args.dit_model_arch}: the point-cloud denoiser takes latents [B, N, C] and has no tri-plane "
+                         "decode / render stage; this entry point draws z as [B, 3C, S, S] and renders tri-planes. Use the class "
+                         "directly (ln3diff_amd.dit.dit_i23d.DiT_models) for point latents")
     return kind
 
 
@@ -124,38 +161,105 @@ def build_models(args, dev, rank):
     dec = Dec(vit_decoder=vit, triplane_decoder=Triplane(img_resolution=args.image_size), cls_token=False, vae_p=2, ldm_z_channels=4,
               ldm_embed_dim=4)
     dit, dec = dit.to(dev), dec.to(dev)
-    ckpts = [p for p in (args.resume_checkpoint, args.ddpm_model_path, args.rec_model_path) if p]
+    got = {'dit': None, 'decoder': None}                  # which file gave each component its weights
     if rank == 0:
-        if not ckpts:
-            fill_module_random_(dit, 0, dev)
-            fill_module_random_(dec, 1, dev)
-            dec.triplane_decoder.decoder.net[2].bias.data[0] += 4.0
-        for p in ckpts:
-            load_checkpoint(p, dit=dit if p != args.rec_model_path else None, decoder=dec if p != args.ddpm_model_path else None)
-    return dit, AE(None, dec, args.image_size), dec
+        plan = [(args.resume_checkpoint, True, True), (args.ddpm_model_path, True, False), (args.rec_model_path, False, True)]
+        for path, want_dit, want_dec in plan:
+            if not path:
+                continue
+            # a joint file holds both components, the single-component files one: load what the file contains, strictly
+            rep = load_checkpoint(path, dit=dit if want_dit else None, decoder=dec if want_dec else None, skip_absent=True)
+            for comp in ('dit', 'decoder'):
+                if comp in rep and rep[comp] != 'absent':
+                    got[comp] = path
+            if all(rep.get(c) in (None, 'absent') for c in ('dit', 'decoder')):
+                raise SystemExit(f"{path}: holds neither denoiser nor decoder tensors under the known prefixes")
+        for comp, mod, seed in (('dit', dit, 0), ('decoder', dec, 1)):
+            if got[comp] is None:
+                # no file for this component: synthetic weights, said out loud (constructor-initialised weights - adaLN-zero etc. -
+                # would produce all-zero denoiser outputs / empty renders without an error)
+                print(f"[entry] WARNING: no checkpoint provides the {comp}: filling it with SYNTHETIC random weights (seed {seed})")
+                fill_module_random_(mod, seed, dev)
+                if comp == 'decoder':
+                    dec.triplane_decoder.decoder.net[2].bias.data[0] += 4.0
+    return dit, AE(None, dec, args.image_size), dec, got
 
 
-def load_conditioning(args, dev):
-    """{'crossattn', 'vector'[, 'concat']} for P prompts: --cond_path tensors, the HIP conditioners on --prompt / --image_path when
-    their checkpoints are given, else synthetic tensors of the right shapes."""
+def load_conditioning(args, dev, objaverse=True):
+    """({'crossattn', 'vector'[, 'concat']} for P prompts, source).  Sources, in order: --cond_path tensors; the HIP conditioners on
+    --prompt (CLIP-L text tower, T23D) / --image_path (OpenCLIP ViT-L/14 + DINOv2 ViT-L/14-reg, I23D) when their checkpoints are
+    given; synthetic tensors of the right shapes ONLY when no prompt / image was asked for.  A prompt or an image that cannot be
+    encoded is refused: sampling from noise conditioning while reporting a normal run would be silently wrong."""
     from .synth import synth_input
+    from .checkpoint import load_checkpoint
     if args.cond_path:
         raw = torch.load(args.cond_path) if args.cond_path.endswith('.pt') else dict(np.load(args.cond_path))
-        return {k: torch.as_tensor(v).float() for k, v in raw.items()}
-    if args.clip_checkpoint and args.prompt and not args.i23d:
+        return {k: torch.as_tensor(v).float() for k, v in raw.items()}, f'tensors from {args.cond_path}'
+    default_prompt = '' if objaverse else 'a red chair'
+    if args.image_path:
+        if not args.i23d:
+            raise SystemExit("--image_path conditions the I23D models: pass --i23d true (and --trainer_name flow_matching)")
+        if args.mv_input:
+            raise SystemExit("--image_path with a multi-view (MV) denoiser: the multi-view conditioner (4 posed views -> 'concat' tokens) "
+                             "is not wired into this entry point; pass the conditioning tensors with --cond_path")
+        if not (args.clip_checkpoint and args.dino_checkpoint):
+            raise SystemExit("--image_path needs --clip_checkpoint (open_clip ViT-L/14 visual tower) and --dino_checkpoint (DINOv2 "
+                             "ViT-L/14-reg): without them the image cannot be encoded (refusing to sample from synthetic conditioning)")
+        from .sgm.image_encoders import FrozenOpenCLIPImageEmbedder, FrozenDinov2ImageEmbedder, I23DConditioner
+        clip, dino = FrozenOpenCLIPImageEmbedder(device=str(dev), output_tokens=True), FrozenDinov2ImageEmbedder(device=str(dev))
+        load_checkpoint(args.clip_checkpoint, conditioner=clip.model)        # strict: an unmapped / missing key raises
+        load_checkpoint(args.dino_checkpoint, conditioner=dino.model)
+        img = _read_image(args.image_path).to(dev)
+        c = I23DConditioner(clip.to(dev), dino.to(dev))(img)
+        return {k: v.float().cpu() for k, v in c.items()}, f'I23DConditioner({args.image_path})'
+    if args.prompt and args.prompt != default_prompt or (args.prompt and args.clip_checkpoint):
+        if args.i23d:
+            raise SystemExit("--prompt conditions the T23D models; the I23D models take --image_path / --cond_path")
+        if not args.clip_checkpoint:
+            raise SystemExit(f"--prompt {args.prompt!r} needs --clip_checkpoint (CLIP-L text tower; plus --tokenizer_dir with vocab.json + "
+                             "merges.txt): without it the prompt cannot be encoded (refusing to sample from synthetic conditioning)")
         from .sgm.encoders import FrozenCLIPEmbedder
-        from .checkpoint import load_checkpoint
         enc = FrozenCLIPEmbedder(device=str(dev), always_return_pooled=True, tokenizer_dir=args.tokenizer_dir or None)
         load_checkpoint(args.clip_checkpoint, conditioner=enc)
         z, pooled = enc.to(dev)([args.prompt])
-        return {'crossattn': z.float().cpu(), 'vector': pooled.float().cpu()}
+        return {'crossattn': z.float().cpu(), 'vector': pooled.float().cpu()}, f'FrozenCLIPEmbedder({args.prompt!r})'
     if args.i23d:
         mv = args.mv_input                # MVCond: CLIP spatial tokens [256, 1024] + multi-view DINO tokens; single view: CLIP || DINO
         c = {'crossattn': synth_input('prompt', (1, 256, 1024 if mv else 2048), args.seed), 'vector': synth_input('vec', (1, 768), args.seed)}
         if mv:
             c['concat'] = synth_input('mv', (1, args.num_mv_views, 256, 1024), args.seed)
-        return c
-    return {'crossattn': synth_input('prompt', (1, 77, args.context_dim), args.seed), 'vector': synth_input('vec', (1, 768), args.seed)}
+        return c, 'synthetic'
+    return ({'crossattn': synth_input('prompt', (1, 77, args.context_dim), args.seed), 'vector': synth_input('vec', (1, 768), args.seed)},
+            'synthetic')
+
+
+def _read_image(path):
+    """[1, 3, H, W] in [-1, 1] from a .npy / .pt array ([H, W, 3] uint8 or [3, H, W] float) or a binary PPM (P6); the preprocessing
+    to 224^2 and the CLIP / DINO normalisation happen in the embedders (sgm/image_encoders.py)."""
+    if path.endswith('.npy') or path.endswith('.pt'):
+        a = torch.as_tensor(np.load(path) if path.endswith('.npy') else torch.load(path))
+    elif path.endswith('.ppm'):
+        with open(path, 'rb') as f:
+            toks = []
+            while len(toks) < 4:
+                line = f.readline()
+                if not line.startswith(b'#'):
+                    toks += line.split()
+            assert toks[0] == b'P6' and int(toks[3]) == 255, "binary 8-bit PPM expected"
+            w, h = int(toks[1]), int(toks[2])
+            a = torch.frombuffer(bytearray(f.read(w * h * 3)), dtype=torch.uint8).reshape(h, w, 3)
+    else:
+        raise SystemExit(f"--image_path {path}: .npy / .pt arrays and binary .ppm are read here (no image codec in this build)")
+    if a.dtype == torch.uint8:
+        a = a.float() / 127.5 - 1.0
+    a = a.float()
+    if a.ndim == 3 and a.shape[-1] == 3:
+        a = a.permute(2, 0, 1)
+    if a.ndim == 3:
+        a = a[None]
+    if a.ndim != 4 or a.shape[1] != 3:
+        raise SystemExit(f"--image_path {path}: expected an RGB image, got shape {tuple(a.shape)}")
+    return a
 
 
 def _save_ppm(path, frame):
@@ -164,9 +268,9 @@ def _save_ppm(path, frame):
         f.write(b'P6 %d %d 255\n' % (f0.shape[1], f0.shape[0]) + f0.tobytes())
 
 
-def run(args):
+def run(args, objaverse=True):
     from . import parallel
-    from .pipeline import T23DPipeline, FlowMatchingEngine, GuidedDiffusionEngine, render_video_given_triplane
+    from .pipeline import T23DPipeline, FlowMatchingEngine, GuidedDiffusionEngine, render_pairs
     from .synth import orbit_cameras
     kind = validate(args)
     rank, local_rank, world = parallel.setup_dist()
@@ -175,66 +279,87 @@ def run(args):
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     os.makedirs(args.logdir, exist_ok=True)
-    if rank == 0:
-        with open(os.path.join(args.logdir, 'args.json'), 'w') as f:
-            json.dump(vars(args), f, indent=2)
-    dit, ae, dec = build_models(args, dev, rank)
+    dit, ae, dec, weights_from = build_models(args, dev, rank)
     parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] + list(dec.buffers()), src=0)
 
-    cond_all = load_conditioning(args, dev)
+    cond_all, cond_src = load_conditioning(args, dev, objaverse)
+    if rank == 0:
+        meta = dict(vars(args), conditioning=cond_src, weights={k: (v or 'synthetic') for k, v in weights_from.items()})
+        with open(os.path.join(args.logdir, 'args.json'), 'w') as f:
+            json.dump(meta, f, indent=2)
     P = cond_all['crossattn'].shape[0]
     cond_all = {k: v.repeat_interleave(args.num_samples, 0) for k, v in cond_all.items()}     # one condition x num_samples
     Bt = P * args.num_samples
     S = int(args.overwrite_diff_inp_size) if args.overwrite_diff_inp_size else args.diffusion_input_size
     torch.manual_seed(args.seed)                                                             # th.manual_seed, then randn(z_shape)
     z_all = torch.randn(Bt, (3 if args.roll_out else 1) * args.denoise_in_channels, S, S)
-    lo, hi = parallel.shard_range(Bt, rank, world)
-    z = z_all[lo:hi].to(dev)
-    cond = {k: v[lo:hi].to(dev) for k, v in cond_all.items()}
     n_cam = 24 if kind == 'flow' else 40                                                      # camera[:24] / 40-view video
     cams = (torch.load(args.pose_path).float() if args.pose_path else orbit_cameras(max(args.num_views, 1)))
     cams = cams[:min(args.num_views, n_cam) if args.pose_path else args.num_views].to(dev)
+    V = cams.shape[0]
 
-    latent = torch.empty(0, *z_all.shape[1:], device=dev)
-    if hi > lo:                                                   # a rank may own no sample (fewer samples than ranks)
+    if kind == 'edm':
+        eng = T23DPipeline(dit, ae, num_steps=args.sample_steps, cfg_scale=args.unconditional_guidance_scale,
+                           triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size)
+    elif kind == 'flow':
+        # the reference's sample_ode default is torchdiffeq dopri5 (atol 1e-6, rtol 1e-3; transport/transport.py:377); --ode_method
+        # defaults to fixed-step euler here (the benchmark configuration) - pass --ode_method dopri5 for the released behaviour
+        eng = FlowMatchingEngine(dit, ae, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
+                                 sampling_method=args.ode_method)
+    else:
+        from .guided_diffusion import gaussian_diffusion as gd
+        from .guided_diffusion.respace import SpacedDiffusion, space_timesteps
+        spec = args.timestep_respacing or str(args.diffusion_steps)
+        if args.use_ddim and not spec.startswith('ddim'):
+            spec = 'ddim' + spec
+        diff = SpacedDiffusion(use_timesteps=space_timesteps(args.diffusion_steps, spec),
+                               betas=gd.get_named_beta_schedule(args.noise_schedule, args.diffusion_steps))
+        eng = GuidedDiffusionEngine(dit, ae, diff, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
+                                    diffusion_input_size=S)
+
+    def sample_fn(lo, hi):                                        # a rank may own no sample (fewer samples than ranks)
+        if hi <= lo:
+            return torch.empty(0, *z_all.shape[1:], device=dev)
+        z = z_all[lo:hi].to(dev)
+        cond = {k: v[lo:hi].to(dev) for k, v in cond_all.items()}
         if kind == 'edm':
-            eng = T23DPipeline(dit, ae, num_steps=args.sample_steps, cfg_scale=args.unconditional_guidance_scale,
-                               triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size)
-            latent = eng.sample_latent(z, cond, None)
-        elif kind == 'flow':
-            eng = FlowMatchingEngine(dit, ae, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
-                                     sampling_method=args.ode_method)
-            latent = eng.sample(cond, None, batch_size=hi - lo, cfg_scale=args.unconditional_guidance_scale,
-                                num_steps=args.sample_steps, zs=z)
-        else:
-            from .guided_diffusion import gaussian_diffusion as gd
-            from .guided_diffusion.respace import SpacedDiffusion, space_timesteps
-            spec = args.timestep_respacing or str(args.diffusion_steps)
-            if args.use_ddim and not spec.startswith('ddim'):
-                spec = 'ddim' + spec
-            diff = SpacedDiffusion(use_timesteps=space_timesteps(args.diffusion_steps, spec),
-                                   betas=gd.get_named_beta_schedule(args.noise_schedule, args.diffusion_steps))
-            eng = GuidedDiffusionEngine(dit, ae, diff, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
-                                        diffusion_input_size=S)
-            latent = eng.sample(cond, batch_size=hi - lo, use_ddim=args.use_ddim, noise=z, clip_denoised=args.clip_denoised,
-                                unconditional_guidance_scale=args.unconditional_guidance_scale)
-        out = render_video_given_triplane(latent.clone(), ae, cams, args.triplane_scaling_divider, export_mesh=args.export_mesh,
-                                          mesh_size=args.mesh_grid, mesh_thres=args.mesh_thres, resolution=args.image_size,
-                                          mesh_path=os.path.join(args.logdir, 'sample%d.obj').replace('%d', '{}') if args.export_mesh else None)
-        if args.export_mesh:                      # mesh_path is formatted with the LOCAL index: rename to the global sample id
-            for i in reversed(range(hi - lo)):
-                src, dst = os.path.join(args.logdir, f'sample{i}.obj'), os.path.join(args.logdir, f'mesh_sample{lo + i}.obj')
-                if os.path.exists(src):
-                    os.replace(src, dst)
-        frames = out['image_raw'].cpu().numpy()
-        np.save(os.path.join(args.logdir, f'latent_rank{rank}.npy'), latent.cpu().numpy())
-        np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), frames)
-        np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), out['image_depth'].cpu().numpy())
+            return eng.sample_latent(z, cond, None)
+        if kind == 'flow':
+            return eng.sample(cond, None, batch_size=hi - lo, cfg_scale=args.unconditional_guidance_scale, num_steps=args.sample_steps, zs=z)
+        return eng.sample(cond, batch_size=hi - lo, use_ddim=args.use_ddim, noise=z, clip_denoised=args.clip_denoised,
+                          unconditional_guidance_scale=args.unconditional_guidance_scale)
+
+    def render_fn(latent_all, pairs):                             # this rank's (sample, view) pairs: views are shared out when Bt < world
+        return render_pairs(latent_all, ae, cams, pairs, args.triplane_scaling_divider, resolution=args.image_size, noise_seed=args.seed)
+
+    lat_all, frames, pairs = parallel.sharded_step(sample_fn, render_fn, Bt, V, rank, world)
+    lo, hi = parallel.shard_range(Bt, rank, world)
+    if args.export_mesh and hi > lo:
+        # meshes go with the SAMPLE shard; the file name carries the global sample id from the start (r2 wrote `sample{local}.obj`
+        # on every rank and renamed afterwards: two ranks raced on the same names)
+        from .mesh import mesh_from_grid
+        mine = lat_all[lo:hi].clone()
+        mine *= args.triplane_scaling_divider
+        d = {'latent_normalized_2Ddiffusion': mine}
+        d.update(ae(latent=d, behaviour='decode_after_vae_no_render'))
+        grid = ae(latent=d, grid_size=args.mesh_grid, behaviour='triplane_decode_grid')
         for i in range(hi - lo):
-            _save_ppm(os.path.join(args.logdir, f'sample{lo + i}_view0.ppm'), frames[i, 0])
-    lat_all = parallel.all_gather_cat(latent)                     # collective: EVERY rank calls it, also with zero rows
+            path = os.path.join(args.logdir, f'mesh_sample{lo + i}.obj')
+            mesh_from_grid(ae.decoder, d, grid['sigma'][i], args.mesh_grid, args.mesh_thres, sample_index=i, path=path)
+            if not os.path.exists(path):
+                raise RuntimeError(f"mesh export of sample {lo + i} produced no file at {path}")
+    np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), frames['image_raw'].cpu().numpy())
+    np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), frames['image_depth'].cpu().numpy())
+    np.save(os.path.join(args.logdir, f'pairs_rank{rank}.npy'), frames['pair_index'].cpu().numpy())      # [P, 2] = (sample, view) of every frame
+    np.save(os.path.join(args.logdir, f'latent_rank{rank}.npy'), lat_all[lo:hi].cpu().numpy())
+    fr = frames['image_raw'].cpu().numpy()
+    for j, (smp, view) in enumerate(frames['pair_index'].tolist()):
+        if view == 0:
+            _save_ppm(os.path.join(args.logdir, f'sample{smp}_view0.ppm'), fr[j])
     if rank == 0:
         np.save(os.path.join(args.logdir, 'latents_all.npy'), lat_all.cpu().numpy())
-        print(f"[rank0] {kind}: sampled {Bt} latents ({P} condition(s) x {args.num_samples}) on {world} GPU(s); outputs in {args.logdir}")
+        print(f"[rank0] {kind}: sampled {Bt} latents ({P} condition(s) x {args.num_samples}) and rendered {Bt * V} views on {world} GPU(s); "
+              f"conditioning: {cond_src}; weights: " + ", ".join(f"{k}={'checkpoint' if v else 'SYNTHETIC'}" for k, v in weights_from.items())
+              + f"; outputs in {args.logdir}")
     parallel.barrier()
     return lat_all

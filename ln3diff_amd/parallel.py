@@ -62,6 +62,38 @@ def shard_range(total, rank, world):
     return lo, min(lo + per, total)
 
 
+def shard_pairs(n_samples, n_views, rank, world):
+    """This rank's share of the n_samples x n_views independent (sample, view) render units, as [(sample, view_lo, view_hi)]:
+    a consecutive range of the sample-major pair list, so with at least as many samples as ranks a rank renders the views of
+    (mostly) its own samples, and with FEWER samples than ranks (--num_samples 4 on 8 GPUs) every rank still renders
+    n_samples * n_views / world views instead of idling through the render (nsr/train_util_diffusion.py:262-283 renders one
+    camera per call: any split is exact)."""
+    lo, hi = shard_range(n_samples * n_views, rank, world)
+    out, p = [], lo
+    while p < hi:
+        s, v0 = divmod(p, n_views)
+        v1 = min(n_views, v0 + (hi - p))
+        out.append((s, v0, v1))
+        p += v1 - v0
+    return out
+
+
+def sharded_step(sample_fn, render_fn, n_samples, n_views, rank, world, gather_frames=False):
+    """One pass of the hot path over a global batch on `world` ranks (bench.py's step and the entry points' body):
+      1. sample_fn(lo, hi) -> latents [hi - lo, ...] of this rank's consecutive share of the samples (0 rows when it owns none);
+      2. ONE all_gather of the latents (49 KB per sample) - the only collective of the step;
+      3. render_fn(latent_all, pairs) -> {name: [P, ...]} for this rank's (sample, view) pairs (shard_pairs);
+      4. optionally the frames of all ranks gathered in pair order ([n_samples * n_views, ...]).
+    Every rank calls it (steps 2 and 4 are collectives), also a rank that owns no sample or no pair."""
+    lo, hi = shard_range(n_samples, rank, world)
+    latent_all = all_gather_cat(sample_fn(lo, hi))
+    pairs = shard_pairs(n_samples, n_views, rank, world)
+    frames = render_fn(latent_all, pairs)
+    if gather_frames:
+        frames = {k: all_gather_cat(v) for k, v in frames.items() if torch.is_tensor(v)}
+    return latent_all, frames, pairs
+
+
 def all_gather_cat(t):
     """Concatenate every rank's rows (dim 0).  Shards may be ragged or EMPTY (fewer samples than ranks): the row counts are
     gathered first, every rank pads to the largest shard, and the padding is dropped after the collective.  All ranks must

@@ -52,6 +52,48 @@ def render_video_given_triplane(planes, rec_model, cams, triplane_scaling_divide
     return out
 
 
+@torch.no_grad()
+def render_pairs(latent_all, rec_model, cams, pairs, triplane_scaling_divider=TRIPLANE_SCALING_DIVIDER, resolution=None, noise_seed=None,
+                 latent_name='latent_normalized_2Ddiffusion'):
+    """The (sample, view) units of one rank (parallel.shard_pairs): decode the samples that occur in `pairs` ONCE, render all
+    listed views in one launch (views_per_call=1: the reference's one-camera-per-call reductions, so a view's pixels do not depend
+    on which other views share the launch).  latent_all [B, 12, 32, 32] is NOT modified.  noise_seed: None draws the stratified /
+    importance noise from the device's default generator in bulk; an int seeds a generator per (sample, view) pair, which makes a
+    frame independent of the world size bit for bit.  Returns {'image_raw' [P,3,R,R], 'image_depth', 'weights_samples',
+    'image_mask', 'pair_index' [P, 2] = (sample, view)}."""
+    from .nsr.triplane import draw_render_noise
+    dev = latent_all.device
+    res = resolution or rec_model.decoder.triplane_decoder.neural_rendering_resolution
+    V_all = cams.shape[0]
+    if not pairs:
+        z = lambda c: torch.empty(0, c, res, res, device=dev)
+        return {'image_raw': z(3), 'image_depth': z(1), 'weights_samples': z(1), 'image_mask': z(1),
+                'pair_index': torch.empty(0, 2, dtype=torch.int64, device=dev)}
+    samples = sorted({s for s, _, _ in pairs})
+    local = {s: i for i, s in enumerate(samples)}
+    planes = latent_all[samples].clone()
+    planes *= triplane_scaling_divider
+    ddpm_latent = {latent_name: planes}
+    ddpm_latent.update(rec_model(latent=ddpm_latent, behaviour='decode_after_vae_no_render'))
+    c = torch.cat([cams[v0:v1] for _, v0, v1 in pairs])
+    pidx = torch.cat([torch.full((v1 - v0,), local[s], dtype=torch.int32, device=dev) for s, v0, v1 in pairs])
+    pair_index = torch.tensor([(s, v) for s, v0, v1 in pairs for v in range(v0, v1)], dtype=torch.int64, device=dev)
+    jitter = u_fine = None
+    if noise_seed is not None:
+        js, us = [], []
+        for s, v in pair_index.tolist():
+            g = torch.Generator(device=dev).manual_seed(int(noise_seed) + s * V_all + v)
+            j, u = draw_render_noise(1, res * res, 64, generator=g, device=dev)
+            js.append(j)
+            us.append(u)
+        jitter, u_fine = torch.cat(js), torch.cat(us)
+    pred = rec_model(img=None, c=c, latent=ddpm_latent, behaviour='triplane_dec', jitter=jitter, u_fine=u_fine, views_per_call=1,
+                     plane_index=pidx, neural_rendering_resolution=res)
+    out = {k: pred[k] for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask')}
+    out['pair_index'] = pair_index
+    return out
+
+
 def _zero_uc(cond):
     """GeneralConditioner.get_unconditional_conditioning(..., force_uc_zero_embeddings=[cond_key]) (encoders/modules.py:161-163,
     sgm_DiffusionEngine.py:448-452): every tensor of the unconditional branch is zeros."""

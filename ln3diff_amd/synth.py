@@ -60,6 +60,19 @@ def fill_module_random_(module, seed=0, device=None):
     return module
 
 
+def load_synth_(module, seed=0):
+    """Fill a module with the deterministic synthetic weights the goldens were made with (synth_state_dict of its own key / shape
+    manifest; computed positional embeddings are kept).  Returns (state_dict, shapes)."""
+    sd = module.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    computed = {k: v for k, v in sd.items() if 'pos_embed' in k}
+    new = synth_state_dict(shapes, seed, computed)
+    module.load_state_dict(new, strict=True)
+    from . import _cache
+    _cache.bump()
+    return new, shapes
+
+
 def synth_state_dict(shapes, seed=0, computed=None):
     """shapes: {name: shape}.  computed: {name: tensor} for deterministic non-random
     entries (pos_embed)."""

@@ -4,8 +4,9 @@ Surface of the reference's transport package for the sampling path: create_trans
 Sampler(transport).sample_ode(sampling_method, num_steps, atol, rtol, reverse)(x, model_fn, **kw) -> [T, ...]
 (transport/__init__.py:3-71, transport/transport.py:374-420, transport/integrators.py:78-120).
 Linear path + velocity prediction: dx/dt = model(x, t), t from 0 (noise) to 1 (data).  Fixed-grid
-'euler' and 'heun' plus an own adaptive Dormand-Prince 5(4) ('dopri5', the reference's default, which lives in the absent
-third-party torchdiffeq: parity unpinned - SURVEY.md §8c; validated by convergence to the fixed-step solution).
+'euler' and 'heun' plus adaptive Dormand-Prince 5(4) with dense output ('dopri5', the reference's default; restated from the
+published algorithm of the absent third-party torchdiffeq 0.2.3: parity unpinned against the package - SURVEY.md §8c; pinned to
+oracle/samplers.py's restatement step for step, and validated by convergence to the fixed-step solution).
 """
 import torch
 
@@ -154,22 +155,39 @@ class Sampler:
         return _sample
 
 
-# ----------------------------------------------------------------------------- adaptive Dormand-Prince 5(4)
+# ----------------------------------------------------------------------------- adaptive Dormand-Prince 5(4), torchdiffeq semantics
+# Restated from torchdiffeq 0.2.3's published algorithm (the package is absent here: PARITY UNPINNED against it; the call site is
+# transport/integrators.py:112-119 `odeint(drift, x, t, method='dopri5', atol, rtol)`, defaults atol 1e-6 / rtol 1e-3 from
+# transport/transport.py:377-380):
+#   * Dormand-Prince-Shampine tableau with FSAL; error estimate dt * sum_i (b5_i - b4_i) k_i;
+#   * error ratio = rms( err / (atol + rtol * max(|y0|, |y1|)) ) over the WHOLE state tensor; accept when <= 1;
+#   * next step = dt * min(10, max(0.9 / ratio^(1/5), 0.2)) (lower bound 1 instead of 0.2 after an accepted step; x 10 when ratio = 0);
+#   * first step from Hairer's heuristic with scale = atol + rtol |y0| and exponent 1/5;
+#   * steps are NOT clipped to the output times: the solver steps past an output time t_i and evaluates the 4th-order
+#     interpolant fitted through (y0, y_mid, y1, f0, f1) of the step that contains it - also for the last output t = 1, so the
+#     model can be evaluated slightly beyond t = 1, as in the reference.
 _DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
 _DP_A = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9],
          [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
          [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
          [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
-_DP_B5 = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0]
-_DP_B4 = [5179 / 57600, 0.0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 1 / 40]
-_DP_E = [b5 - b4 for b5, b4 in zip(_DP_B5, _DP_B4)]
+_DP_E = [35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 + 12231 / 42400,
+         11 / 84 - 649 / 6300, -1.0 / 60.0]
+_DP_MID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+           187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
 
 
-def _dopri5_sampler(num_steps, atol, rtol, safety=0.9, ifactor=10.0, dfactor=0.2, max_steps=1000):
-    """Own Dormand-Prince 5(4) with FSAL, RMS error norm over the whole state, the usual 0.9*err^(-1/5) controller
-    (factor clamped to [0.2, 10]) and Hairer's initial-step heuristic.  Steps are clipped to the requested output
-    times t = linspace(0, 1, num_steps) (so no dense-output interpolation is needed and the model is never evaluated
-    outside [0, 1]); the trajectory at those times is returned like the reference's odeint call."""
+def dopri5_next_step(dt, ratio, accepted, safety=0.9, ifactor=10.0, dfactor=0.2):
+    """torchdiffeq's _optimal_step_size (order 5)."""
+    if ratio == 0:
+        return dt * ifactor
+    return dt * min(ifactor, max(safety / ratio ** 0.2, 1.0 if accepted else dfactor))
+
+
+def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
+    """Device implementation: every stage / error / interpolant is one ln3d_lincomb launch, the weighted error norm one
+    ln3d_err_ratio_sq launch; the accept / step-size decision is host-side (one scalar read-back per attempted step).
+    Times are Python floats (fp64), the state fp32 - torchdiffeq's own mixed precision."""
     ts = [float(v) for v in torch.linspace(0.0, 1.0, num_steps)]
 
     @torch.no_grad()
@@ -186,49 +204,63 @@ def _dopri5_sampler(num_steps, atol, rtol, safety=0.9, ifactor=10.0, dfactor=0.2
 
         def rms(err, y0, y1):
             ops.err_ratio_sq(err, y0, y1, atol, rtol, acc)
-            return (float(acc.item()) / n) ** 0.5                       # host sync: the step-size decision is host-side
+            return (float(acc.item()) / n) ** 0.5
 
         k = [None] * 7
-        k[0] = f(0.0, y)
-        # initial step (Hairer, Norsett, Wanner II.4), order 5
-        zero = torch.zeros_like(y)
+        k[0] = f(ts[0], y)
+        # _select_initial_step(func, t0, y0, order = 4, rtol, atol, norm, f0)
         d0, d1 = rms(y, y, None), rms(k[0], y, None)
         h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
         y1 = torch.empty_like(y)
         ops.lincomb(y, [k[0]], [h0], y1)
-        f1 = f(h0, y1)
+        f1 = f(ts[0] + h0, y1)
         df = torch.empty_like(y)
         ops.lincomb(None, [f1, k[0]], [1.0, -1.0], df)
         d2 = rms(df, y, None) / h0
         h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
-        h = min(100 * h0, h1)
-        traj = [y.clone()] if return_trajectory else None
-        t, nfe, steps = 0.0, 2, 0
-        ynew, err, ystage = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        dt = min(100 * h0, h1)
+        nfe, steps, accepted = 2, 0, 0
+        t0 = t1 = ts[0]                                    # the interval the interpolant covers (empty before the first step)
+        y0i, f0i = y.clone(), k[0]                          # left end of that interval
+        y1b, ymid = torch.empty_like(y), torch.empty_like(y)
+        ca, cb, cc = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        err, ystage = torch.empty_like(y), torch.empty_like(y)
+        dti = 0.0
+        out = [y.clone()]
         for t_out in ts[1:]:
-            while t < t_out - 1e-12:
+            while t_out > t1:                               # _advance: step until the accepted interval reaches the output time
                 if steps >= max_steps:
                     raise RuntimeError("dopri5: max_steps exceeded")
-                hh = min(h, t_out - t)
-                for s in range(1, 7):
-                    ops.lincomb(y, k[:s], [hh * a for a in _DP_A[s]], ystage)
-                    if s < 6:
-                        k[s] = f(t + _DP_C[s] * hh, ystage)
+                ta = t1                                     # attempt a step from the end of the last accepted one
+                for s_ in range(1, 7):
+                    ops.lincomb(y, k[:s_], [dt * a for a in _DP_A[s_]], ystage)
+                    if s_ < 6:
+                        k[s_] = f(ta + _DP_C[s_] * dt, ystage)
                     else:
-                        ynew.copy_(ystage)                              # stage 7 input == 5th-order solution (FSAL)
-                        k[6] = f(t + hh, ynew)
+                        y1b.copy_(ystage)                   # FSAL: the last stage's input is the 5th-order solution
+                        k[6] = f(ta + dt, y1b)
                 nfe += 6
-                ops.lincomb(None, k, [hh * e for e in _DP_E], err)
-                ratio = rms(err, y, ynew)
+                ops.lincomb(None, k, [dt * e for e in _DP_E], err)
+                ratio = rms(err, y, y1b)
                 steps += 1
-                if ratio <= 1.0:
-                    t += hh
-                    y.copy_(ynew)
+                ok = ratio <= 1.0
+                if ok:
+                    accepted += 1
+                    # _interp_fit(y0, y1, k, dt)
+                    ops.lincomb(y, k, [dt * m for m in _DP_MID], ymid)
+                    ops.lincomb(None, [k[6], k[0], y1b, y, ymid], [2 * dt, -2 * dt, -8.0, -8.0, 16.0], ca)
+                    ops.lincomb(None, [k[0], k[6], y, y1b, ymid], [5 * dt, -3 * dt, 18.0, 14.0, -32.0], cb)
+                    ops.lincomb(None, [k[6], k[0], y, y1b, ymid], [dt, -4 * dt, -11.0, -5.0, 16.0], cc)
+                    y0i.copy_(y)
+                    f0i, dti = k[0], dt
+                    t0, t1 = ta, ta + dt
+                    y.copy_(y1b)
                     k[0] = k[6]
-                fac = ifactor if ratio == 0 else min(ifactor, max(safety * ratio ** -0.2, 1.0 if ratio < 1 else dfactor))
-                h = hh * fac if ratio > 1.0 or hh == h else max(h, hh * fac)
-            if return_trajectory:
-                traj.append(y.clone())
-        sample.last_stats = {'nfe': nfe, 'steps': steps}
-        return torch.stack(traj, 0) if return_trajectory else y[None]
+                dt = dopri5_next_step(dt, ratio, ok)
+            xq = (t_out - t0) / (t1 - t0)
+            yo = torch.empty_like(y)
+            ops.lincomb(None, [y0i, f0i, cc, cb, ca], [1.0, xq * dti, xq ** 2, xq ** 3, xq ** 4], yo)     # _interp_evaluate
+            out.append(yo)
+        sample.last_stats = {'nfe': nfe, 'steps': steps, 'accepted': accepted, 't_end': t1}
+        return torch.stack(out, 0) if return_trajectory else out[-1][None]
     return sample

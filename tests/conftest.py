@@ -41,13 +41,8 @@ def rel_l2(a, b):
 
 def load_synth(module, seed=0):
     """Fill a module with the deterministic synthetic weights used by the goldens."""
-    from ln3diff_amd.synth import synth_state_dict
-    sd = module.state_dict()
-    shapes = {k: tuple(v.shape) for k, v in sd.items()}
-    computed = {k: v for k, v in sd.items() if 'pos_embed' in k}
-    new = synth_state_dict(shapes, seed, computed)
-    module.load_state_dict(new, strict=True)
-    return new, shapes
+    from ln3diff_amd.synth import load_synth_
+    return load_synth_(module, seed)
 
 
 @pytest.fixture(scope="session")

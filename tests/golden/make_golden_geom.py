@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Round-3 golden vectors: parity at the BENCHMARKED launch geometry and at the configs that so far were covered by
+property tests only.  Produced by the REFERENCE's own Python in the build container (see make_golden.py
+for the rules; the reference does not travel), each section checks oracle/ against it in the same pass.
+
+    python tests/golden/make_golden_geom.py [edm_step1] [flow_step1] [render512] [xl2_edm10] [grid192]
+
+  edm_step1   DiT-L/2 T23D: ONE EulerEDM + CFG 6.5 step (the first of the 250-step schedule) for 8 different samples, each run by
+              the reference at B = 1.  The GPU test runs the 8 samples as ONE batch (network batch 16 x 768 = 12 288 GEMM rows,
+              256 attention heads - bench.py's geometry) and compares every sample with its own reference output.
+  flow_step1  DiT-PixArt-L/2 I23D: the first flow-matching Euler step of sample_ode('euler', 50) with forward_with_cfg(4.0), for 4
+              samples at B = 1.  The GPU test tiles them to B = 32 (network batch 64 x 1024 = 65 536 rows, 1024-key attention).
+  render512   one 512^2 view of the reference Triplane.forward (BASELINE configs[4]): sub-sampled fp16 images + full statistics.
+  xl2_edm10   DiT-XL/2 (configs[3]): EulerEDM 10 steps + CFG 6.5, B = 1: first step and final latent.
+  grid192     the 192^3 sigma / rgb grid of the reference's triplane_decode_grid path (renderer._run_model in 2^16-point chunks,
+              vit_triplane.py:2009-2050): every 8th sample per axis (fp16), statistics, and the count of cells above the
+              marching-cubes threshold 10 (nsr/train_util_diffusion.py:221-233).
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402  (installs the shims)
+import make_golden_render as mgr  # noqa: E402
+from ln3diff_amd.synth import synth_input, orbit_cameras  # noqa: E402
+from oracle import dit as odit, samplers as osamp, render as orender  # noqa: E402
+
+torch.set_grad_enabled(False)
+check, save, load_synth = mg.check, mg.save, mg.load_synth
+
+
+def _edm(steps):
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    sampler = EulerEDMSampler(discretization_config=dc, num_steps=steps,
+                              guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG', 'params': {'scale': 6.5}},
+                              device='cpu')
+    den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                           num_idx=1000, discretization_config=dc, do_append_zero=False, quantize_c_noise=True, flip=True)
+    return sampler, den
+
+
+def sec_edm_step1():
+    print('== DiT-L/2 T23D: first EulerEDM-250 + CFG 6.5 step, 8 samples, each by the reference at B = 1')
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = mg.build_t23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    sampler, den = _edm(250)
+    denoiser = lambda x, s, c: den(lambda xx, t, cc, **kw: m(xx, t, cc), x, s, c)
+    outs = []
+    t0 = time.time()
+    for i in range(8):
+        z = synth_input('z', (1, 12, 32, 32), 41 + i)
+        cond = {'crossattn': synth_input('c', (1, 77, 768), 41 + i), 'vector': synth_input('v', (1, 768), 41 + i)}
+        uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+        # one sampler_step of the reference loop (sampling.py:109-130): prepare_sampling_loop, then step 0
+        x, s_in, sigmas, num_sigmas, cond_, uc_ = sampler.prepare_sampling_loop(z.clone(), cond, uc, 250)
+        x1 = sampler.sampler_step(s_in * sigmas[0], s_in * sigmas[1], denoiser, x, cond_, uc_, 0.0)
+        outs.append(x1)
+        if i == 0:
+            sig, table = osamp.legacy_ddpm_sigmas(250), osamp.discrete_denoiser_table()
+            xo = z * torch.sqrt(1.0 + sig[0] ** 2.0)
+            dn = osamp.edm_denoise_cfg(lambda xx, t, c: odit.t23d_forward(sd, xx, t, c, heads), xo, sig[:1], cond, uc, 6.5, table)
+            check('oracle first step', xo + (xo - dn) / sig[0] * (sig[1] - sig[0]), x1, 5e-5)
+    print(f'  reference: {time.time() - t0:.0f}s')
+    # sample 0 must be the `first` trajectory point of the committed 250-step golden
+    g = np.load(os.path.join(HERE, 'full_edm_ditl2_250.npz'))
+    check('sample 0 == full_edm_ditl2_250.first', outs[0], torch.from_numpy(g['first']), 1e-6)
+    save('edm_step1_ditl2_b8', x1=torch.cat(outs), seeds=np.arange(41, 49))
+
+
+def sec_flow_step1():
+    print('== DiT-PixArt-L/2 I23D: first flow-matching Euler step (num_steps 50), CFG 4.0, 4 samples at B = 1')
+    from transport import create_transport, Sampler
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = mg.build_i23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    t_grid = torch.linspace(0, 1, 50)           # torchdiffeq-style fixed grid of sample_ode('euler', num_steps=50) (integrators.py:98-119)
+    outs, vels = [], []
+    t0 = time.time()
+    for i in range(4):
+        z = synth_input('z', (1, 12, 32, 32), 42 + i)
+        zs = torch.cat([z, z], 0)
+        cond = {'crossattn': synth_input('ca', (1, 256, 2048), 42 + i), 'vector': synth_input('v', (1, 768), 42 + i)}
+        uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+        context = {k: torch.cat([cond[k], uc[k]], 0) for k in cond}
+        t = torch.ones(2) * t_grid[0]
+        v = m.forward_with_cfg(zs, t, context=context, cfg_scale=4.0)          # the drift of a Linear-path velocity model (transport.py:207-221)
+        x1 = zs + (t_grid[1] - t_grid[0]) * v
+        outs.append(x1[:1])
+        vels.append(v[:1])
+        if i == 0:
+            v_or = odit.i23d_forward_with_cfg(sd, zs, t, context, 4.0, heads)
+            check('oracle forward_with_cfg', v_or, v, 5e-5)
+    print(f'  reference: {time.time() - t0:.0f}s')
+    # the same step through the reference's own sampler object, for sample 0 (pins the grid / dt convention)
+    tr = create_transport(path_type='Linear', prediction='velocity', snr_type='lognorm')
+    z = synth_input('z', (1, 12, 32, 32), 42)
+    cond = {'crossattn': synth_input('ca', (1, 256, 2048), 42), 'vector': synth_input('v', (1, 768), 42)}
+    context = {k: torch.cat([cond[k], torch.zeros_like(cond[k])], 0) for k in cond}
+    fn = Sampler(tr).sample_ode(sampling_method='euler', num_steps=2)          # a 2-point grid: one Euler step of size 1
+    y = fn(torch.cat([z, z], 0), m.forward_with_cfg, context=context, cfg_scale=4.0)[-1][:1]
+    check('sampler euler step == x + dt v', z + vels[0], y, 1e-6)
+    save('flow_step1_pixartl2_b4', x1=torch.cat(outs), v=torch.cat(vels), seeds=np.arange(42, 46), dt=np.array(float(t_grid[1] - t_grid[0])))
+
+
+def sec_render512():
+    print('== renderer at 512^2 (BASELINE configs[4]; reference Triplane.forward)')
+    res = 512
+    tp = mgr.build_triplane(res)
+    sd = mgr.dense_decoder_sd(0)
+    tp.decoder.load_state_dict(sd, strict=True)
+    planes = synth_input('planes', (1, 96, 128, 128), 3, 4.0)
+    cams = orbit_cameras(24)[[7]]
+    torch.manual_seed(0)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = tp(planes, cams)
+    print(f'  {res}^2: reference {time.time() - t0:.0f}s, mask mean {float(r["image_mask"].mean()):.3f}')
+    st = 8
+    save(f'render_full_r{res}', image_raw_sub=r['image_raw'][:, :, ::st, ::st].half(),
+         image_depth_sub=r['image_depth'][:, :, ::st, ::st].half(), weights_sub=r['weights_samples'][:, :, ::st, ::st].half(),
+         rgb_mean=r['image_raw'].mean((0, 2, 3)), rgb_sq=(r['image_raw'] ** 2).mean((0, 2, 3)),
+         depth_mean=r['image_depth'].mean(), depth_min=r['image_depth'].min(), depth_max=r['image_depth'].max(),
+         w_mean=r['weights_samples'].mean(), cams=cams, jitter_seed=np.array(0), stride=np.array(st))
+
+
+def sec_xl2_edm10():
+    print('== DiT-XL/2 T23D (configs[3]): EulerEDM 10 + CFG 6.5, B = 1')
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-XL/2']
+    m = mg.build_t23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    sampler, den = _edm(10)
+    z = synth_input('z', (1, 12, 32, 32), 43)
+    cond = {'crossattn': synth_input('c', (1, 77, 768), 43), 'vector': synth_input('v', (1, 768), 43)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    t0 = time.time()
+    y_ref = sampler(lambda x, s, c: den(lambda xx, t, cc, **kw: m(xx, t, cc), x, s, c), z.clone(), cond, uc)
+    print(f'  reference loop {time.time() - t0:.0f}s; final std {float(y_ref.std()):.3f}')
+    trace = []
+    y_or = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads), z.clone(), cond, uc, 10, 6.5, trace)
+    check('DiT-XL/2 EulerEDM-10 final latent', y_or, y_ref, 2e-4)
+    save('edm10_ditxl2', final=y_ref, first=trace[0], s5=trace[5])
+
+
+def sec_grid192():
+    print('== 192^3 sigma / rgb grid (reference renderer._run_model in 2^16-point chunks)')
+    tp = mgr.build_triplane(16)
+    sd = mgr.dense_decoder_sd(0)
+    sd['net.2.bias'][0] += 6.0            # sigma bias 10: the iso-level 10 of the reference's mesh export cuts through the synthetic volume
+    tp.decoder.load_state_dict(sd, strict=True)
+    planes = synth_input('planes', (1, 96, 128, 128), 3, 4.0)
+    G = 192
+    ax = torch.linspace(-0.45, 0.45, G)
+    pts = torch.stack(torch.meshgrid(ax, ax, ax, indexing='ij'), dim=-1).reshape(1, -1, 3)
+    sig, rgb = [], []
+    t0 = time.time()
+    pl = planes.reshape(1, 3, 32, 128, 128)
+    for i in range(0, pts.shape[1], 2 ** 16):
+        c = pts[:, i:i + 2 ** 16]
+        out = tp.renderer._run_model(planes=pl, decoder=tp.decoder, sample_coordinates=c, sample_directions=torch.zeros_like(c),
+                                     options=tp.rendering_kwargs)
+        sig.append(out['sigma'])
+        rgb.append(out['rgb'])
+    sigma = torch.cat(sig, 1).reshape(G, G, G)
+    rgb = torch.cat(rgb, 1).reshape(G, G, G, 3)
+    print(f'  reference: {time.time() - t0:.0f}s; sigma mean {float(sigma.mean()):.3f}, > 10: {int((sigma > 10).sum())}')
+    g = orender.decode_grid(planes, sd, G)
+    check('grid192 sigma', g['sigma'].reshape(G, G, G), sigma, 1e-5)
+    check('grid192 rgb', g['rgb'].reshape(G, G, G, 3), rgb, 1e-5)
+    save('grid192', sigma_sub=sigma[::8, ::8, ::8].half(), rgb_sub=rgb[::8, ::8, ::8].half(), sigma_mean=sigma.mean(),
+         sigma_sq=(sigma ** 2).mean(), rgb_mean=rgb.mean((0, 1, 2)), n_above_10=np.array(int((sigma > 10).sum())),
+         sigma_max=sigma.max(), sigma_min=sigma.min(), sigma_bias=np.array(10.0))
+
+
+SECTIONS = {'edm_step1': sec_edm_step1, 'flow_step1': sec_flow_step1, 'render512': sec_render512, 'xl2_edm10': sec_xl2_edm10,
+            'grid192': sec_grid192}
+
+if __name__ == '__main__':
+    for s in (sys.argv[1:] or list(SECTIONS)):
+        t0 = time.time()
+        SECTIONS[s]()
+        print(f'-- {s} done in {time.time() - t0:.1f}s', flush=True)

@@ -43,6 +43,49 @@ def test_unrunnable_flag_combinations_are_refused(flags, msg):
     assert msg in str(e.value)
 
 
+@pytest.mark.parametrize("flags,msg", [
+    (("--mixed_prediction", "True"), "mixed prediction"),
+    (("--ae_classname", "vit.vit_triplane.SomethingElse"), "released decoder class"),
+    (("--vae_p", "4"), "vae_p = 2"),
+    (("--denoise_out_channels", "8"), "denoise_out_channels"),
+    (("--out_chans", "48"), "3 planes x 32"),
+    (("--i23d", "true", "--trainer_name", "flow_matching", "--dit_model_arch", "DiT-PixArt-MV-PCD-L"), "point-cloud denoiser"),
+])
+def test_model_describing_flags_are_checked_not_dropped(flags, msg):
+    """Flags of the released launchers that describe the model / prediction type (they used to fall into the unused
+    bucket): accepted at the released values, refused with the reason otherwise."""
+    with pytest.raises(SystemExit) as e:
+        validate(_args(True, *flags))
+    assert msg in str(e.value)
+
+
+def test_released_launcher_values_of_checked_flags_pass():
+    # sample_obajverse_t23d_dit.sh: --pred_type v --predict_v True --mixed_prediction False --patch_size 14 --vae_p 2 ... with sgm_legacy
+    a = _args(True, "--pred_type", "v", "--predict_v", "True", "--mixed_prediction", "False", "--patch_size", "14", "--vae_p", "2",
+              "--denoise_out_channels", "4", "--decoder_in_chans", "32", "--out_chans", "96", "--triplane_in_chans", "32", "--decoder_output_dim", "3",
+              "--ae_classname", "vit.vit_triplane.RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder")
+    assert validate(a) == 'edm'                     # the sgm engine never reads predict_v / pred_type (the reference neither)
+    with pytest.raises(SystemExit) as e:            # ... the guided_diffusion engines do: ModelMeanType.V is not built
+        validate(_args(False, "--predict_v", "True"))
+    assert "epsilon only" in str(e.value)
+
+
+def test_conditioning_is_never_silently_synthetic():
+    """a prompt / image that cannot be encoded is refused; synthetic conditioning is labelled as such."""
+    from ln3diff_amd.entry import load_conditioning
+    c, src = load_conditioning(_args(True), 'cpu', True)
+    assert src == 'synthetic' and c['crossattn'].shape == (1, 77, 768)
+    c, src = load_conditioning(_args(False), 'cpu', False)              # the second script's DEFAULT prompt: allowed, labelled
+    assert src == 'synthetic'
+    for flags, msg in ((("--prompt", "a blue car"), "--clip_checkpoint"),
+                       (("--i23d", "true", "--image_path", "/tmp/x.npy"), "--clip_checkpoint"),
+                       (("--image_path", "/tmp/x.npy"), "--i23d"),
+                       (("--i23d", "true", "--prompt", "a blue car"), "T23D")):
+        with pytest.raises(SystemExit) as e:
+            load_conditioning(_args(True, *flags), 'cpu', True)
+        assert msg in str(e.value), (flags, str(e.value))
+
+
 def test_trainer_table_covers_the_reference_names():
     for name in ('sgm_legacy', 'flow_matching', 'adm', 'vpsde_crossattn'):
         assert name in TRAINERS

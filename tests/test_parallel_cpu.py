@@ -68,6 +68,78 @@ def test_world2_gloo_broadcast_shard_gather():
         assert ok_b and ok_g and t == 2.0, (rank, ok_b, ok_g, t)
 
 
+def _stub_sample_fn(z_all):
+    """Stand-in for "denoise my samples": a deterministic per-sample function of the globally seeded noise."""
+    def fn(lo, hi):
+        return torch.tanh(z_all[lo:hi] * 1.7) + 0.25
+    return fn
+
+
+def _stub_render_fn(n_views):
+    """Stand-in for decode + render of (sample, view) pairs: frame = f(latent of that sample, view index)."""
+    def fn(latent_all, pairs):
+        fr = [latent_all[s].mean(0, keepdim=True) * (1.0 + 0.125 * v) for s, v0, v1 in pairs for v in range(v0, v1)]
+        idx = torch.tensor([(s, v) for s, v0, v1 in pairs for v in range(v0, v1)], dtype=torch.int64).reshape(-1, 2)
+        img = torch.stack(fr) if fr else torch.empty(0, 1, *latent_all.shape[2:])
+        return {'image_raw': img, 'pair_index': idx}
+    return fn
+
+
+def _worker_step(rank, world, port, q, n_samples, n_views):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from ln3diff_amd import parallel
+    parallel.setup_dist('gloo')
+    z_all = torch.randn(n_samples, 12, 4, 4, generator=torch.Generator().manual_seed(41))
+    lat, frames, pairs = parallel.sharded_step(_stub_sample_fn(z_all), _stub_render_fn(n_views), n_samples, n_views, rank, world,
+                                               gather_frames=True)
+    n_mine = sum(v1 - v0 for _, v0, v1 in pairs)
+    parallel.barrier()
+    q.put((rank, lat.numpy(), frames['image_raw'].numpy(), frames['pair_index'].numpy(), n_mine))      # numpy: pickled by value
+
+
+def _run_world(world, n_samples, n_views):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_step, args=(r, world, port, q, n_samples, n_views)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+def test_sharded_step_samples_and_views_over_2_4_8_ranks():
+    """bench.py's step (parallel.sharded_step) on stub sample / render functions: 4 samples x 40 views on 8 ranks (fewer samples
+    than ranks: the render is shared out by (sample, view) pairs), and ragged cases on 2 and 4 ranks.  Every pair is rendered
+    exactly once, every rank has work, and latents and frames equal the single-process result bit for bit."""
+    from ln3diff_amd import parallel
+    for world, n_samples, n_views in ((8, 4, 40), (4, 6, 5), (2, 3, 7)):
+        z_all = torch.randn(n_samples, 12, 4, 4, generator=torch.Generator().manual_seed(41))
+        lat1, fr1, pairs1 = parallel.sharded_step(_stub_sample_fn(z_all), _stub_render_fn(n_views), n_samples, n_views, 0, 1)
+        assert pairs1 == [(s, 0, n_views) for s in range(n_samples)]
+        res = _run_world(world, n_samples, n_views)
+        counts = [r[4] for r in res]
+        assert sum(counts) == n_samples * n_views and min(counts) >= (n_samples * n_views) // world - 1 and min(counts) > 0, counts
+        for rank, lat, img, idx, _ in res:
+            assert torch.equal(torch.from_numpy(lat), lat1)                  # one all_gather: every rank holds all latents
+            assert idx.tolist() == [[s, v] for s in range(n_samples) for v in range(n_views)]      # each pair once, in order
+            assert torch.equal(torch.from_numpy(img), fr1['image_raw'])
+
+
+def test_shard_pairs_cover_every_pair_once():
+    from ln3diff_amd.parallel import shard_pairs
+    for n_samples, n_views in ((1, 1), (4, 40), (8, 40), (3, 24), (16, 24)):
+        for world in (1, 2, 3, 4, 8):
+            got = [(s, v) for r in range(world) for s, v0, v1 in shard_pairs(n_samples, n_views, r, world) for v in range(v0, v1)]
+            assert got == [(s, v) for s in range(n_samples) for v in range(n_views)]
+            sizes = [sum(v1 - v0 for _, v0, v1 in shard_pairs(n_samples, n_views, r, world)) for r in range(world)]
+            assert max(sizes) - min(s for s in sizes if s) <= (n_samples * n_views + world - 1) // world
+
+
 def test_shard_range_partitions():
     from ln3diff_amd.parallel import shard_range
     for total in (1, 7, 8, 64):
