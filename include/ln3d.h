@@ -25,6 +25,9 @@ extern "C" {
 
 const char* ln3d_strerror(int code);
 int ln3d_abi_version(void);
+/* The measurement switches (environment variables LN3D_GEMM_TILE, LN3D_GEMM_ABL, LN3D_ATTN_*) are read ONCE per
+ * process, at the first launch that consults them.  A harness that changes them afterwards calls this to have them re-read. */
+void ln3d_reload_env(void);
 
 /* ---------------------------------------------------------------- GEMM with fused epilogues
  * out[m, n] = epilogue( sum_k X[m,k] * W[n,k] + bias[n] ),  X:[M,K] bf16 (tokens), W:[N,K] bf16
@@ -78,9 +81,17 @@ typedef struct {
    * M % tokens == 0, M >= 1536, N >= 128 (the head-aligned tiles); otherwise LN3D_ERR_UNSUPPORTED - run ln3d_rmsnorm_heads_bf16
    * after the GEMM instead.  NULL = no normalisation. */
   const float* head_norm0; const float* head_norm1; float head_norm_eps;
+  /* GATE_RES (ABI 7): optional per-sample row added to the residual AFTER gating, res_bias[(m / gate_rows) * res_bias_ld + n] (f32):
+   *   out0[m, n] += gate * (acc + bias) + res_bias.   Carries the cross-attention output of samples whose context rows are all
+   *   identical (the zero embeddings of the unconditional CFG branch, sgm_DiffusionEngine.py:448-452): softmax over identical keys
+   *   is uniform, so that sub-block is the constant to_out(v) + b per sample and layer, and its two GEMMs are skipped for them. */
+  const float* res_bias; int64_t res_bias_ld;
 } ln3d_gemm_args;
 
 int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);
+/* 1 when ln3d_gemm_bf16's HEADS epilogue will apply head_norm0/1 itself for this problem (the tile the library picks is
+ * head-aligned), 0 when the caller has to run ln3d_rmsnorm_heads_bf16 after the GEMM. */
+int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int head_dim_pad);
 
 /* ---------------------------------------------------------------- fused attention
  * O[b, q, h*Dh + d] = softmax_k(scale * Q.K^T) V, bf16 in/out, fp32 softmax, MFMA 32x32x16.

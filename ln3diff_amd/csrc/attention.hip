@@ -1250,6 +1250,8 @@ static const AttnCfg& attn_cfg() {
   return g_attn_cfg;
 }
 
+extern "C" void ln3d_attn_reload_env(void) { g_attn_cfg.ver = -1; }
+
 static int launch_attn_short(const AttnP& p, hipStream_t s) {
   // one query tile per wave (128 queries per workgroup): twice the workgroups, so load, compute and store phases of
   // different workgroups overlap on a CU (the kernel is a latency-bound stream of Q in / O out); LN3D_ATTN_QT=2 for A/B runs

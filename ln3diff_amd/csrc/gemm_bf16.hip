@@ -38,7 +38,13 @@ struct GemmP {
   int tokens, tok_pad, heads, head_dim, transpose_mask, head_dim_pad;
   int ctx_keys, ctx_pad; float ctx_scale_log2;
   const float* hn0; const float* hn1; float hn_eps;   // HEADS: fused qk_norm weights (outputs 0 / 1) or NULL
-  int abl;   // bench-only ablation bits of the ring kernel (LN3D_GEMM_ABL): 1 = skip the epilogue, 2 = 2 K-stages only, 4 = no DMA in steady state
+  const float* rb; int64_t rb_ld;                      // GATE_RES: per-sample row added after gating (sample = row / gate_rows) or NULL
+  // Measurement bits of the ring kernel (LN3D_GEMM_ABL, read once per process; 0 in every product run): 1 = skip the epilogue,
+  // 2 = 2 K-stages only, 4 = no DMA in steady state.  They stay RUNTIME branches on purpose: r3 compiled them out and hipcc's register
+  // allocation of the 12-wave QKV tile (168-VGPR cap) went from 13 spilled registers outside the K loop to 73 with scratch traffic
+  // inside it (bench 2.49 -> 2.23 samples/s); neither unroll pragmas, an opaque loop start nor 32-bit DMA offsets brought the old
+  // allocation back, the two never-taken branches do.
+  int abl;
 };
 
 template <int EPI>
@@ -66,6 +72,10 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
     if (p.gate) {
       const float4 g = *reinterpret_cast<const float4*>(p.gate + (int64_t)(tok / p.gate_rows) * p.gate_ld + fb);
       v0 *= g.x; v1 *= g.y; v2 *= g.z; v3 *= g.w;
+    }
+    if (p.rb) {
+      const float4 r = *reinterpret_cast<const float4*>(p.rb + (int64_t)(tok / p.gate_rows) * p.rb_ld + fb);
+      v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
     }
     float4* xp = reinterpret_cast<float4*>((float*)p.out0 + (int64_t)tok * p.ldo + fb);
     float4 x = *xp;
@@ -228,6 +238,7 @@ struct RunEpi {
   bf16_t* hbase; int64_t hwrap; int hrows_left; int hstride;
   // GATE_RES
   float4 g0, g1; int grows_left;
+  float4 r0, r1;            // res_bias rows of the run's first sample / the next one
 
   __device__ __forceinline__ void init_feature(const GemmP& p, int fb, int& which, int& h, int& d) const {
     const int dm = p.heads * p.head_dim;
@@ -249,20 +260,29 @@ struct RunEpi {
     }
     if constexpr (EPI == LN3D_EPI_GATE_RES) {
       g0 = g1 = make_float4(1.f, 1.f, 1.f, 1.f);
+      r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
       grows_left = 1 << 30;
-      if (p.gate) {
+      if (p.gate || p.rb) {
         generic = p.gate_rows < 32;
         const int s0 = tb / p.gate_rows;
         grows_left = p.gate_rows - (tb - s0 * p.gate_rows);
-        g0 = *reinterpret_cast<const float4*>(p.gate + (int64_t)s0 * p.gate_ld + fb);
-        if (grows_left < 32 && tb + grows_left < p.M) g1 = *reinterpret_cast<const float4*>(p.gate + (int64_t)(s0 + 1) * p.gate_ld + fb);
+        const bool two = grows_left < 32 && tb + grows_left < p.M;
+        if (p.gate) {
+          g0 = *reinterpret_cast<const float4*>(p.gate + (int64_t)s0 * p.gate_ld + fb);
+          if (two) g1 = *reinterpret_cast<const float4*>(p.gate + (int64_t)(s0 + 1) * p.gate_ld + fb);
+        }
+        if (p.rb) {
+          r0 = *reinterpret_cast<const float4*>(p.rb + (int64_t)s0 * p.rb_ld + fb);
+          if (two) r1 = *reinterpret_cast<const float4*>(p.rb + (int64_t)(s0 + 1) * p.rb_ld + fb);
+        }
       }
     }
   }
   // GATE_RES with the residual quad already in registers (staged_epilogue prefetches the 8 rows of a block in one batch)
   __device__ __forceinline__ void apply_res(const GemmP& p, int tb, int row, int fb, float4 v, float4 x) const {
     const float4 g = row >= grows_left ? g1 : g0;
-    x.x += (v.x + bias.x) * g.x; x.y += (v.y + bias.y) * g.y; x.z += (v.z + bias.z) * g.z; x.w += (v.w + bias.w) * g.w;
+    const float4 r = row >= grows_left ? r1 : r0;
+    x.x += (v.x + bias.x) * g.x + r.x; x.y += (v.y + bias.y) * g.y + r.y; x.z += (v.z + bias.z) * g.z + r.z; x.w += (v.w + bias.w) * g.w + r.w;
     *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb) = x;
     if (p.out1) {
       uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
@@ -277,9 +297,10 @@ struct RunEpi {
     } else if constexpr (EPI == LN3D_EPI_GATE_RES) {
       if (generic) { epilogue4<EPI>(p, tb + row, fb, v.x, v.y, v.z, v.w); return; }
       const float4 g = row >= grows_left ? g1 : g0;
+      const float4 r = row >= grows_left ? r1 : r0;
       float4* xp = reinterpret_cast<float4*>((float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb);
       float4 x = *xp;
-      x.x += (v.x + bias.x) * g.x; x.y += (v.y + bias.y) * g.y; x.z += (v.z + bias.z) * g.z; x.w += (v.w + bias.w) * g.w;
+      x.x += (v.x + bias.x) * g.x + r.x; x.y += (v.y + bias.y) * g.y + r.y; x.z += (v.z + bias.z) * g.z + r.z; x.w += (v.w + bias.w) * g.w + r.w;
       *xp = x;
       if (p.out1) {
         uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
@@ -332,7 +353,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
    if constexpr (NI % 2 == 0) {
     // Interior tiles (every tile of the DiT shapes): branch-free, so that hipcc's counted vmcnt waits let block b+1's batch
     // stay in flight while block b is stored (behind exec-masked range checks it falls back to vmcnt(0) per block).
-    const bool full = (tw0 + 32 * NJ <= p.M) && (fw0 + 32 * NI <= p.N) && !(p.gate && p.gate_rows < 32);
+    const bool full = (tw0 + 32 * NJ <= p.M) && (fw0 + 32 * NI <= p.N) && !((p.gate || p.rb) && p.gate_rows < 32);
     if (__builtin_amdgcn_readfirstlane(full ? 1 : 0)) {
       auto fetch = [&](int blk, float4 (&xr)[8]) __attribute__((always_inline)) {
         const float* base = (const float*)p.out0 + (int64_t)(tw0 + (blk % NJ) * 32 + rrow) * p.ldo + fw0 + (blk / NJ) * 64 + 4 * rc;
@@ -588,7 +609,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
 
   // DMA instruction idx = 8 rows x 128 B (W rows first, then X rows) -> LDS bytes [idx*1024, +1024) of the slot
   const int r8 = lane >> 3;
-  const bf16_t* src[NPW];
+  // source of DMA instruction q: a wave-uniform base (W or X: SGPR pair) + a 32-bit lane offset - one VGPR per instruction instead
+  // of a 64-bit pointer (the 12-wave tiles run at the 168-register cap: r3 found hipcc spilling 34 registers per K stage there)
+  const char* sbase[NPW]; uint32_t soff[NPW];
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
     const int idx = wid * NPW + q;
@@ -596,15 +619,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
     if (idx < BF / 8) {
       int r = f0 + rt; r = r < p.N ? r : p.N - 1;
-      src[q] = p.W + (int64_t)r * p.ldw + chunk * 8;
+      sbase[q] = reinterpret_cast<const char*>(p.W + (int64_t)f0 * p.ldw);
+      soff[q] = (uint32_t)(((int64_t)(r - f0) * p.ldw + chunk * 8) * 2);
     } else {
       int r = t0 + rt; r = r < p.M ? r : p.M - 1;
-      src[q] = p.X + (int64_t)r * p.ldx + chunk * 8;
+      sbase[q] = reinterpret_cast<const char*>(p.X + (int64_t)t0 * p.ldx);
+      soff[q] = (uint32_t)(((int64_t)(r - t0) * p.ldx + chunk * 8) * 2);
     }
   }
   const int dst0 = wid * NPW * 1024;
 #define Y_ISSUE1(s, q)                                                                                       \
-  __builtin_amdgcn_global_load_lds((glb_void_t*)(src[q] + (s) * 64),                                          \
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(sbase[q] + (s) * 128 + soff[q]),                             \
       (lds_void_t*)(smem + ((s) & 1) * STAGEB + dst0 + (q) * 1024), 16, 0, 0)
 
   const int key = (l31 >> 1) & 7;
@@ -628,11 +653,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   // before the epilogue needs them.  Row r of head hh at XK + hh*XKH + r*128, 16-byte chunk c at c ^ ((r >> 1) & 7).
   constexpr int XK = 2 * STAGEB, XKH = 96 * 128;
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) {
-    static_assert(NI == 2 && NJ == 3 && WGT == 2 && NW == 8, "one head (64 features) per wave row, 256x192 tile");
+    static_assert(NI == 2 && NJ == 3 && WGT == 2 && (NW == 8 || NW == 4), "one head (64 features) per wave row: 256x192 (8 waves) or 128x192 (4 waves) tile");
     const int bsmp = t0 / p.tokens;
     const int nrows8 = (p.ctx_keys + 7) >> 3;                      // DMA instructions (8 rows each) per head
     const bf16_t* kc = (const bf16_t*)p.out1 + ((int64_t)bsmp * p.heads + (f0 >> 6)) * p.ctx_pad * 64;
-    for (int idx = wid; idx < 4 * nrows8; idx += NW) {
+    for (int idx = wid; idx < WGF * nrows8; idx += NW) {
       const int hh = idx / nrows8, j = idx - hh * nrows8;
       const int r = 8 * j + (lane >> 3);
       const bf16_t* src_k = kc + ((int64_t)hh * p.ctx_pad + r) * 64 + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
@@ -702,7 +727,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     __builtin_amdgcn_s_barrier();                     // ring retired: V^T tiles of the 4 heads go to its start
     {
       const bf16_t* vc = (const bf16_t*)p.out2 + ((int64_t)bsmp * p.heads + (f0 >> 6)) * 64 * p.ctx_pad;
-      for (int idx = wid; idx < 4 * nkb * 8; idx += NW) {         // (head, key block, 8 pieces of 8 rows)
+      for (int idx = wid; idx < WGF * nkb * 8; idx += NW) {       // (head, key block, 8 pieces of 8 rows)
         const int hh = idx / (nkb * 8), rem = idx - hh * nkb * 8, kb = rem >> 3, j = rem & 7;
         const int vrow = 8 * j + (lane >> 3);
         const bf16_t* src_v = vc + ((int64_t)hh * 64 + vrow) * p.ctx_pad + kb * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) << 3);
@@ -909,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
 template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
-  constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? 4 * 96 * 128 : 0);
+  constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? (NW / WGT) * 96 * 128 : 0);
   static_assert(2 * (BF + BT) * 128 >= NW * 8192 && LDSB <= 163840, "staging regions live in the ring");
   static bool attr_set = false;
   if (!attr_set) {
@@ -939,7 +964,7 @@ static int launch(const GemmP& p, hipStream_t s) {
 // 3 per SIMD), 11 = 384f x 192t with 8 waves (96x96 wave tiles; kept for A/B runs)
 template <int EPI>
 static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
-  if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
+  if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return cfg == 14 ? launch_ring64<EPI, 4, 2, 2, 3>(p, s) : launch_ring64<EPI, 8, 2, 2, 3>(p, s);
   else
   switch (cfg) {
     case 7: return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
@@ -969,24 +994,50 @@ static int num_cus() {
 // throughput of the tile shape (measured at K = 1024 on MI355X: 256x256 1.00, 256x192 0.95, 128x384 0.945 - the L2 -> LDS
 // fill is the limiter, so throughput follows the tile's flop/byte).  DiT-L/2 at 12288 tokens: N = 4096 -> 256x256 (3 full
 // rounds), N = 3072 -> 384x192 with 12 waves (2 full rounds), N = 1024 -> 256x192 (1 full round).
+// LN3D_GEMM_TILE (measurement switch, read once per process): s = the 128x128 register-staged kernel, x<cfg> = that ring configuration
+static int g_gemm_abl = -1, g_gemm_forced = -2;           // environment switches, parsed once (ln3d_reload_env() re-reads them)
+static int gemm_abl() {
+  if (g_gemm_abl < 0) { const char* e = getenv("LN3D_GEMM_ABL"); g_gemm_abl = e ? atoi(e) : 0; }
+  return g_gemm_abl;
+}
+static int forced_cfg() {
+  if (g_gemm_forced == -2) {
+    const char* e = getenv("LN3D_GEMM_TILE");
+    g_gemm_forced = !e ? -1 : (e[0] == 's' ? 0 : (e[0] == 'x' ? atoi(e + 1) : -1));
+  }
+  return g_gemm_forced;
+}
+extern "C" void ln3d_gemm_reload_env(void) { g_gemm_abl = -1; g_gemm_forced = -2; }
 static int pick_cfg(int M, int N, bool head_aligned = false) {
-  const char* force = getenv("LN3D_GEMM_TILE");
-  if (force && force[0] == 's') return 0;
-  if (force && force[0] == 'x') return atoi(force + 1);
+  if (forced_cfg() >= 0) return forced_cfg();
   if (!(M >= 1536 && N >= 128)) return 0;
   static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
                                                                {8, 128, 384, 0.945f}};
   const int cus = num_cus();
-  int best = 8; float best_cost = 1e30f;
+  int best = 8; float best_cost = 1e30f; int64_t best_tiles = 0;
   for (int i = 0; i < 4; ++i) {
     // head split with 64-wide heads: only the configurations whose wave row is ONE head (64 features, NI = 2) have the
     // head-contiguous staged epilogue; at the I23D shapes (65536 x 3072) 256x256 costs 550 us against 500 (384x192)
     if (head_aligned && C[i].cfg == 7) continue;
     const int64_t tiles = (int64_t)((N + C[i].bf - 1) / C[i].bf) * ((M + C[i].bt - 1) / C[i].bt);
     const float cost = (float)((tiles + cus - 1) / cus) * (float)(C[i].bf * C[i].bt) / C[i].speed;
-    if (cost < best_cost) { best_cost = cost; best = C[i].cfg; }
+    if (cost < best_cost) { best_cost = cost; best = C[i].cfg; best_tiles = tiles; }
+  }
+  // Under-filled launch (the best 8-wave tiling leaves half the CUs idle - the conditional half of a CFG batch, M = 6144 x
+  // N = 1024: 128 tiles of 256x192): 128x192 tiles with 4 waves double the tile count.  r3: 22.5 us vs 27.0 (GATE_RES), 15.7 vs 21.1
+  // (plain); at full M the two tie (35.9 vs 36.2), so it is only taken here.
+  if (best_tiles * 2 <= cus) {
+    const int64_t t14 = (int64_t)((N + 127) / 128) * ((M + 191) / 192);
+    if (t14 > best_tiles) best = 14;
   }
   return best;
+}
+
+extern "C" int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int head_dim_pad) {
+  if (head_dim_pad <= 0) head_dim_pad = head_dim;
+  if (!(head_dim == 64 && head_dim_pad == 64 && tokens > 0 && (tokens & 31) == 0 && (M % tokens) == 0 && (N % 64) == 0)) return 0;
+  const int cfg = pick_cfg(M, N, true);
+  return (cfg == 8 || cfg == 9 || cfg == 12 || cfg == 14) ? 1 : 0;
 }
 
 extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
@@ -1003,8 +1054,9 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.transpose_mask = a->transpose_mask;
   p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
   p.ctx_keys = a->ctx_keys; p.ctx_pad = a->ctx_pad; p.ctx_scale_log2 = a->ctx_scale * 1.4426950408889634f;
+  p.abl = gemm_abl();
   p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
-  { const char* e = getenv("LN3D_GEMM_ABL"); p.abl = e ? atoi(e) : 0; }
+  p.rb = a->epilogue == LN3D_EPI_GATE_RES ? a->res_bias : nullptr; p.rb_ld = a->res_bias_ld;
   hipStream_t s = (hipStream_t)stream;
   const int cfg = pick_cfg(a->M, a->N, a->epilogue == LN3D_EPI_HEADS && a->head_dim == 64 && a->head_dim_pad <= 64);
   switch (a->epilogue) {
@@ -1019,7 +1071,8 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
           (a->tokens % 192) != 0 || (a->M % a->tokens) != 0 || a->ctx_keys <= 0 || a->ctx_keys > 96 || a->ctx_pad < a->ctx_keys ||
           (a->ctx_pad % 64) != 0 || (a->N % 256) != 0)
         return LN3D_ERR_BAD_ARG;
-      return run_cfg<LN3D_EPI_CROSS_ATTN>(p, s, 9);
+      // 256x192 tiles (8 waves); when they would leave half the chip idle, 128x192 tiles with 4 waves (2 heads per tile)
+      return run_cfg<LN3D_EPI_CROSS_ATTN>(p, s, ((int64_t)(a->N / 256) * ((a->M + 191) / 192) * 2 <= num_cus() && forced_cfg() != 9) ? 14 : 9);
     case LN3D_EPI_GATE_RES: return run_cfg<LN3D_EPI_GATE_RES>(p, s, cfg);
     case LN3D_EPI_F32_SILU:
       if (!a->out1) return LN3D_ERR_BAD_ARG;
@@ -1028,7 +1081,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
       if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens)
         return LN3D_ERR_BAD_ARG;
       if ((a->head_norm0 || a->head_norm1) &&
-          !((cfg == 8 || cfg == 9 || cfg == 12) && a->head_dim == 64 && p.head_dim_pad == 64 && (a->tokens & 31) == 0 &&
+          !((cfg == 8 || cfg == 9 || cfg == 12 || cfg == 14) && a->head_dim == 64 && p.head_dim_pad == 64 && (a->tokens & 31) == 0 &&
             (a->M % a->tokens) == 0 && (a->N % 64) == 0))
         return LN3D_ERR_UNSUPPORTED;                  // only the head-aligned staged epilogue normalises
       return run_cfg<LN3D_EPI_HEADS>(p, s, cfg);

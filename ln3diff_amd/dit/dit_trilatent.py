@@ -181,7 +181,27 @@ class DiT_TriLatent(DiT):
         # K copy whose 64 head dims are stored in the 16-group order [0-3, 8-11, 4-7, 12-15]: the order in which the query
         # projection's accumulators hand q to the MFMA when cross-attention runs inside that GEMM (LN3D_EPI_CROSS_ATTN)
         kp_all = k_all[..., ops.vt_key_order(dh, dev)].contiguous()
-        return {'k': k_all, 'kp': kp_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn}
+        cc = {'k': k_all, 'kp': kp_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'fold': 0}
+        # Samples whose context rows are all IDENTICAL - the zero embeddings of the unconditional CFG branch (force_uc_zero_embeddings,
+        # sgm_DiffusionEngine.py:448-452; the caption MLP turns them into 77 copies of one row): every key of such a sample is the same
+        # vector, softmax over identical scores is uniform whatever the query, and the cross-attention sub-block is the constant
+        # to_out(v) + b per (layer, sample).  For a leading run of such samples ([uc, c] order) the constants are computed here, once
+        # per prompt, with the same kernels (bf16 V row -> to_out GEMM, fp32 accumulate), and forward() adds them in the epilogue of
+        # the preceding GEMM instead of running to_q / attention / to_out on those rows (LN3D_NO_UC_FOLD=1: off).
+        if not os.environ.get('LN3D_NO_UC_FOLD') and Lc > 1 and Bn > 1:
+            same = (context == context[:, :1]).flatten(1).all(1)                 # [Bn]: one host read per prompt
+            fold = 0
+            for v in same.tolist():
+                if not v:
+                    break
+                fold += 1
+            if 0 < fold < Bn:
+                const = torch.zeros(self.depth, Bn, D, dtype=torch.float32, device=dev)      # rows >= fold stay 0
+                for i, q in enumerate(P['blocks']):
+                    v_row = vt_all[i, :fold, :, :, 0].reshape(fold, H * dh).contiguous()     # V^T[b, h, d, key 0] = the attention output
+                    ops.gemm(v_row, q['co_w'], q['co_b'], ops.EPI_F32, const[i, :fold])
+                cc['fold'], cc['const'] = fold, const
+        return cc
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -253,21 +273,25 @@ class DiT_TriLatent(DiT):
         probe = getattr(self, '_fc1_probe', None)
         fused_cross = (N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
                        and not os.environ.get('LN3D_NO_FUSED_CROSS'))
+        fold = cc.get('fold', 0)
+        r0 = fold * N                                          # first token row that still runs the cross-attention GEMMs
         for i, q in enumerate(P['blocks']):
             o6 = i * 6 * D
             sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
             sh_m, sc_m, g_m = mod[:, o6 + 3 * D:], mod[:, o6 + 4 * D:], mod[:, o6 + 5 * D:]
             ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=nmod)
             ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
-            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=nmod)
-            # cross attention on x (no pre-norm, no gate; reference :318)
+            # samples [0, fold) have a constant cross-attention output (prepare_context): it rides on this epilogue as a per-sample row
+            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=nmod,
+                     res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
+            # cross attention on x (no pre-norm, no gate; reference :318) for the remaining samples
             if fused_cross:     # q projection + attention over the cached text context in ONE kernel (q stays in registers)
-                ops.gemm(xb, q['cq_w'], None, ops.EPI_CROSS_ATTN, oc, cc['kp'][i], cc['vt'][i], M=M, tokens=N, heads=H,
+                ops.gemm(xb[r0:], q['cq_w'], None, ops.EPI_CROSS_ATTN, oc[r0:], cc['kp'][i][fold:], cc['vt'][i][fold:], M=M - r0, tokens=N, heads=H,
                          head_dim=64, ctx_keys=cc['Lc'], ctx_pad=cc['lpad'], ctx_scale=64 ** -0.5)
             else:
-                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
-                ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
-            ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
+                ops.gemm(xb[r0:], q['cq_w'], None, ops.EPI_HEADS, qc, M=M - r0, tokens=N, tok_pad=N, heads=H, head_dim=64)
+                ops.attention(qc, cc['k'][i][fold:], cc['vt'][i][fold:], oc[r0:], Bn - fold, H, N, N, cc['Lc'], cc['lpad'], 64)
+            ops.gemm(oc[r0:], q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt[r0:])
             ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=nmod)
             if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
                 # measurement hook (bench.py): HIP events on the launch stream around this one GEMM, inside the real step

@@ -81,6 +81,7 @@ def create_argparser(objaverse=True):
     d.update({k: v[0] for k, v in _CHECKED.items()})
     ap = argparse.ArgumentParser(allow_abbrev=False)
     add_dict_to_argparser(ap, d)
+    ap.set_defaults(entry_objaverse=objaverse)             # which script's defaults these are (the default --prompt differs)
     return ap
 
 
@@ -268,7 +269,8 @@ def _save_ppm(path, frame):
         f.write(b'P6 %d %d 255\n' % (f0.shape[1], f0.shape[0]) + f0.tobytes())
 
 
-def run(args, objaverse=True):
+def run(args, objaverse=None):
+    objaverse = getattr(args, 'entry_objaverse', True) if objaverse is None else objaverse
     from . import parallel
     from .pipeline import T23DPipeline, FlowMatchingEngine, GuidedDiffusionEngine, render_pairs
     from .synth import orbit_cameras
@@ -348,8 +350,12 @@ def run(args, objaverse=True):
             mesh_from_grid(ae.decoder, d, grid['sigma'][i], args.mesh_grid, args.mesh_thres, sample_index=i, path=path)
             if not os.path.exists(path):
                 raise RuntimeError(f"mesh export of sample {lo + i} produced no file at {path}")
-    np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), frames['image_raw'].cpu().numpy())
-    np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), frames['image_depth'].cpu().numpy())
+    # frames_rank{r}.npy: [samples of this rank, V, 3, R, R] when the rank's pairs are whole samples (always with >= 1 sample per
+    # rank), else the flat pair list [P, 3, R, R]; pairs_rank{r}.npy names the (sample, view) of every frame either way
+    whole = all(v0 == 0 and v1 == V for _, v0, v1 in pairs)
+    shp = (lambda t: t.reshape(len(pairs), V, *t.shape[1:])) if (whole and pairs) else (lambda t: t)
+    np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), shp(frames['image_raw']).cpu().numpy())
+    np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), shp(frames['image_depth']).cpu().numpy())
     np.save(os.path.join(args.logdir, f'pairs_rank{rank}.npy'), frames['pair_index'].cpu().numpy())      # [P, 2] = (sample, view) of every frame
     np.save(os.path.join(args.logdir, f'latent_rank{rank}.npy'), lat_all[lo:hi].cpu().numpy())
     fr = frames['image_raw'].cpu().numpy()

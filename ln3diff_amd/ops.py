@@ -23,9 +23,14 @@ def _chk_dev(*ts):
             raise RuntimeError("ln3diff_amd ops need device tensors (no CPU fallback exists)")
 
 
+def reload_env():
+    """Re-read the library's measurement switches (LN3D_GEMM_TILE, LN3D_ATTN_V, ...: they are parsed once per process)."""
+    L.lib().ln3d_reload_env()
+
+
 def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, gate=None, gate_rows=1,
          gate_ld=0, tokens=0, tok_pad=0, heads=0, head_dim=0, transpose_mask=0, head_dim_pad=0, ctx_keys=0, ctx_pad=0,
-         ctx_scale=0.0, head_norm0=None, head_norm1=None, head_norm_eps=1e-5):
+         ctx_scale=0.0, head_norm0=None, head_norm1=None, head_norm_eps=1e-5, res_bias=None, res_bias_ld=0):
     """out = epi(x[M,K] @ w[N,K]^T + bias).  x, w bf16 (row stride = shape[-1])."""
     _chk_dev(x, w, out0)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -45,14 +50,17 @@ def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, 
     a.head_dim_pad = head_dim_pad
     a.ctx_keys, a.ctx_pad, a.ctx_scale = ctx_keys, ctx_pad, float(ctx_scale)
     a.head_norm0, a.head_norm1, a.head_norm_eps = _p(head_norm0), _p(head_norm1), float(head_norm_eps)
+    a.res_bias, a.res_bias_ld = _p(res_bias), int(res_bias_ld)
     L.check(L.lib().ln3d_gemm_bf16(C.byref(a), _stream()), "gemm")
 
 
 def heads_norm_fusable(M, N, tokens, head_dim, head_dim_pad=0):
-    """True when ln3d_gemm_bf16's HEADS epilogue can apply qk_norm itself (include/ln3d.h): the head-aligned ring tiles."""
+    """True when ln3d_gemm_bf16's HEADS epilogue applies qk_norm itself for this problem - the library's own answer (it depends on
+    the tile configuration it picks), not a copy of its heuristic."""
     import os
-    return (head_dim == 64 and head_dim_pad in (0, 64) and M >= 1536 and N >= 128 and N % 64 == 0 and tokens % 32 == 0 and
-            M % tokens == 0 and not os.environ.get('LN3D_GEMM_TILE') and not os.environ.get('LN3D_NO_FUSED_QKNORM'))
+    if os.environ.get('LN3D_NO_FUSED_QKNORM'):
+        return False
+    return bool(L.lib().ln3d_gemm_heads_norm_fusable(int(M), int(N), int(tokens), int(head_dim), int(head_dim_pad)))
 
 
 def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causal=False):

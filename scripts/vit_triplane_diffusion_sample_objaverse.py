@@ -14,4 +14,4 @@ if __name__ == '__main__':
     args, unknown = create_argparser(objaverse=True).parse_known_args()
     if unknown:
         print(f"[entry] {len(unknown)} launcher flag(s) not used by the sampling path: {' '.join(u for u in unknown if u.startswith('--'))}")
-    run(args, objaverse=True)
+    run(args)

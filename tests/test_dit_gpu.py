@@ -82,3 +82,46 @@ def test_t23d_pixart_forward_with_cfg_vs_reference_golden(hip_lib, tag):
     e = rel_l2(y, g['y'])
     print('t23d pixart', tag, e)
     assert e < 2e-2, e
+
+
+@pytest.mark.parametrize("arch,B", [('DiT-L/2', 8), ('DiT-B/2', 3), ('DiT-XL/2', 2)])
+def test_unconditional_branch_fold_is_exact_algebra(hip_lib, arch, B, monkeypatch):
+    """Samples whose context rows are all identical (the ZERO embeddings of the unconditional CFG half, force_uc_zero_embeddings in
+    sgm_DiffusionEngine.py:448-452) have a query-independent cross-attention output: prepare_context() computes that constant per
+    (layer, sample) and forward() adds it in the proj GEMM's epilogue instead of running to_q / attention / to_out on those rows.
+    Checked against the same network with the fold switched off (every sample through the attention kernels), against the CPU
+    oracle, and on a batch whose 'unconditional' half is NOT uniform (nothing may be folded)."""
+    from ln3diff_amd.dit.dit_trilatent import DiT_models
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    from ln3diff_amd.synth import synth_input
+    from oracle import dit as odit
+    m = DiT_models[arch](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768, roll_out=True, vit_blk=TextCondDiTBlock)
+    sd, _ = load_synth(m, 0)
+    m = m.cuda()
+    heads = m.num_heads
+    x = synth_input('x', (B, 12, 32, 32), 5).cuda()
+    x2 = torch.cat([x, x])
+    t = torch.full((2 * B,), 617.0).cuda()
+    c = synth_input('c', (B, 77, 768), 5).cuda()
+    ctx = torch.cat([torch.zeros_like(c), c])                         # VanillaCFG order [uc, c]
+    cc = m.prepare_context(ctx)
+    assert cc['fold'] == B and cc['const'].shape == (m.depth, 2 * B, m.embed_dim) and float(cc['const'][:, B:].abs().max()) == 0.0
+    y_fold = m(x2, t, context_cache=cc)
+    monkeypatch.setenv('LN3D_NO_UC_FOLD', '1')
+    cc0 = m.prepare_context(ctx)
+    assert cc0['fold'] == 0
+    y_full = m(x2, t, context_cache=cc0)
+    monkeypatch.delenv('LN3D_NO_UC_FOLD')
+    e = rel_l2(y_fold, y_full)
+    print(arch, 'fold vs no fold', e, 'uncond half', rel_l2(y_fold[:B], y_full[:B]), 'cond half', rel_l2(y_fold[B:], y_full[B:]))
+    assert e < 1e-3, e                                                # the same arithmetic up to GEMM tile shape / summation order
+    if arch != 'DiT-L/2':                                             # oracle forward on the CPU: the smaller cases only
+        y_or = odit.t23d_forward(sd, x2[:2].cpu(), t[:2].cpu(), torch.cat([ctx[:1], ctx[B:B + 1]]).cpu(), heads)
+        assert rel_l2(y_fold[[0, B]].cpu(), y_or) < TOL
+    # a different prompt in the first half: rows differ inside a sample, nothing is folded, same result as the unfolded path
+    ctx2 = torch.cat([synth_input('c', (B, 77, 768), 6).cuda(), c])
+    cc2 = m.prepare_context(ctx2)
+    assert cc2['fold'] == 0 and 'const' not in cc2
+    # only a LEADING run is folded: zeros in the second half stay on the attention path
+    cc3 = m.prepare_context(torch.cat([c, torch.zeros_like(c)]))
+    assert cc3['fold'] == 0

@@ -121,8 +121,8 @@ def test_dopri5_matches_the_oracle_restatement_step_for_step(hip_lib):
     torchdiffeq is absent, so the semantics (steps not clipped to the output grid, 4th-order dense output, rms error norm, step
     controller constants, Hairer's first step) are restated twice from its published algorithm - oracle/samplers.py on the CPU,
     ln3diff_amd/transport on the device - and compared here: same number of network evaluations and of accepted / rejected
-    steps, the same overshoot beyond t = 1, and the final latent within the bf16-network tolerance.  An analytic ODE checks the
-    solver itself to 1e-6 without any network."""
+    steps on an fp32 vector field, overshoot beyond t = 1, and - through the tiny I23D network - the final latent within the
+    bf16-network tolerance.  An analytic ODE checks the solver itself to 1e-6 without any network."""
     from oracle import dit as odit, samplers as osamp
     from ln3diff_amd.synth import synth_input
     from ln3diff_amd.transport import Sampler, create_transport
@@ -142,10 +142,26 @@ def test_dopri5_matches_the_oracle_restatement_step_for_step(hip_lib):
     traj = fn(zz.cuda(), m.forward_with_cfg, context_cache=cache, cfg_scale=4.0)
     assert traj.shape[0] == 50
     print('dopri5 oracle', st, 'hip', fn.last_stats, 'final rel-l2', rel_l2(traj[-1].cpu(), y_or))
-    assert fn.last_stats['nfe'] == st['nfe'] and fn.last_stats['steps'] == st['steps'] and fn.last_stats['accepted'] == st['accepted']
-    assert abs(fn.last_stats['t_end'] - st['t_end']) < 1e-3 * st['t_end'] and st['t_end'] >= 1.0
-    assert rel_l2(traj[-1].cpu(), y_or) < 1e-2
-    # analytic: dy/dt = -2 y + sin(3 t) through the device solver (model_fn is any callable on device tensors)
+    assert rel_l2(traj[-1].cpu(), y_or) < 1e-2                        # measured 1.7e-3
+    # The step SEQUENCE depends on the error estimate, and at rtol 1e-3 that estimate sees the bf16 rounding of the network
+    # (~1e-3 of |v|): the HIP path accepts smaller steps than the fp32 oracle (measured 5 steps / 32 evaluations vs 3 / 20).  Both
+    # overshoot t = 1 and interpolate back, as torchdiffeq does.
+    assert st['t_end'] >= 1.0 and fn.last_stats['t_end'] >= 1.0 and fn.last_stats['nfe'] <= 3 * st['nfe']
+    # Step-for-step equality of the two restatements on a vector field that is the SAME fp32 arithmetic on both sides (elementwise
+    # torch ops): number of evaluations, of attempted and accepted steps, the end of the last step, and all 50 outputs.
+    field = lambda y, t, **kw: torch.sin(3.0 * t)[:, None, None, None] * y - 0.3 * y * y * y + torch.cos(y * 2.0)
+    y0 = synth_input('y0', (2, 12, 32, 32), 7)
+    for rtol in (1e-3, 1e-5):
+        so = {}
+        outs_o = []
+        yo = osamp.flow_ode_dopri5(field, y0, 50, 1e-6, rtol, so)
+        fh = Sampler(create_transport()).sample_ode(num_steps=50, atol=1e-6, rtol=rtol)
+        th = fh(y0.cuda(), field)
+        print('dopri5 fp32 field rtol', rtol, 'oracle', so, 'hip', fh.last_stats, 'final', rel_l2(th[-1].cpu(), yo))
+        assert (fh.last_stats['nfe'], fh.last_stats['steps'], fh.last_stats['accepted']) == (so['nfe'], so['steps'], so['accepted'])
+        assert abs(fh.last_stats['t_end'] - so['t_end']) < 1e-4 * so['t_end']
+        assert rel_l2(th[-1].cpu(), yo) < 1e-5
+    # analytic: dy/dt = -2 y + sin(3 t) through the device solver
     y0 = torch.tensor([[1.0, -0.5, 2.0, 0.25]] * 2).cuda()
     lin = lambda y, t, **kw: -2.0 * y + torch.sin(3.0 * t)[:, None]
     fa = Sampler(create_transport()).sample_ode(num_steps=11, atol=1e-9, rtol=1e-7)

@@ -11,7 +11,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x11", "x12"])
+@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x11", "x12", "x14"])
 def ops(hip_lib, request):
     """Every kernel test runs with the GEMM tile selection left to the library and forced to each tile config."""
     import os
@@ -21,11 +21,13 @@ def ops(hip_lib, request):
         os.environ.pop("LN3D_GEMM_TILE", None)
     else:
         os.environ["LN3D_GEMM_TILE"] = {"large": "l", "small": "s"}.get(request.param, request.param)
+    o.reload_env()                    # the library parses its switches once per process
     yield o
     if old is None:
         os.environ.pop("LN3D_GEMM_TILE", None)
     else:
         os.environ["LN3D_GEMM_TILE"] = old
+    o.reload_env()
 
 
 def _bf(t):
@@ -93,6 +95,37 @@ def test_gemm_gate_residual(ops, rows_per_gate):
     assert rel_l2(acc2, res + xb.float() @ wb.float().t() + b) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,rows", [(192, 256, 128, 96), (2304, 1024, 1024, 768), (6144, 1024, 1024, 768), (12288, 1024, 1024, 768),
+                                         (3000, 1152, 1024, 750)])
+def test_gemm_gate_residual_with_sample_rows(ops, M, N, K, rows):
+    """GATE_RES with the ABI-7 per-sample row (res_bias): out0 += gate * (x W^T + b) + res_bias[sample], at the small-kernel shape,
+    at the 128x192 / 4-wave tiling (under-filled launches: M = 2304, 6144), at the benchmarked 256x192 tiling (M = 12288, interior
+    tiles: the double-buffered residual prefetch) and at a ragged shape whose 32-token runs cross sample boundaries."""
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.05).to(dev), torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ns = M // rows
+    gate = torch.randn(ns, 2 * N, generator=g).to(dev)[:, N:]
+    rb = torch.randn(ns, N, generator=g).to(dev)
+    rb[ns // 2:] = 0                                                   # the conditional half carries zero rows
+    xb, wb = _bf(x), _bf(w)
+    lin = xb.float() @ wb.float().t() + b
+    ref = res + gate.repeat_interleave(rows, 0) * lin + rb.repeat_interleave(rows, 0)
+    acc = res.clone()
+    copy = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc, copy, gate=gate, gate_rows=rows, gate_ld=2 * N, res_bias=rb, res_bias_ld=N)
+    assert rel_l2(acc, ref) < 2e-5, rel_l2(acc, ref)
+    assert rel_l2(copy.float(), ref) < 4e-3
+    acc2 = res.clone()                                                 # no gate, only the rows
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc2, gate_rows=rows, res_bias=rb, res_bias_ld=N)
+    assert rel_l2(acc2, res + lin + rb.repeat_interleave(rows, 0)) < 2e-5
+    acc3, acc4 = res.clone(), res.clone()                              # bit-repeatable
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc3, gate=gate, gate_rows=rows, gate_ld=2 * N, res_bias=rb, res_bias_ld=N)
+    ops.gemm(xb, wb, b, ops.EPI_GATE_RES, acc4, gate=gate, gate_rows=rows, gate_ld=2 * N, res_bias=rb, res_bias_ld=N)
+    assert torch.equal(acc3, acc4) and torch.equal(acc3, acc)
+
+
 def test_gemm_heads_split(ops):
     dev = 'cuda'
     B, T, H, Dh, K = 2, 77, 4, 64, 128
@@ -130,8 +163,9 @@ def test_gemm_heads_split_with_fused_qk_norm(ops, B, T, H, K):
     xb, wb = _bf(x), _bf(w)
     import os
     forced = os.environ.get('LN3D_GEMM_TILE')
-    assert ops.heads_norm_fusable(B * T, 3 * H * Dh, T, Dh) == (forced is None)
-    if forced not in (None, 'x8', 'x9', 'x12'):          # tiles without the head-aligned epilogue refuse
+    small = B * T < 1536                                  # below the ring kernels' size: the 128x128 kernel has no fused qk_norm
+    assert ops.heads_norm_fusable(B * T, 3 * H * Dh, T, Dh) == (forced in (None, 'x8', 'x9', 'x12', 'x14') and not (small and forced is None))
+    if forced not in (None, 'x8', 'x9', 'x12', 'x14') or (small and forced is None):          # tiles without the head-aligned epilogue refuse
         with pytest.raises(RuntimeError):
             ops.gemm(xb, wb, b, ops.EPI_HEADS, torch.zeros(B, H, T, Dh, device=dev, dtype=torch.bfloat16), None, None, M=B * T, tokens=T,
                      tok_pad=T, heads=H, head_dim=Dh, head_norm0=nq)
@@ -338,13 +372,15 @@ def test_sampler_steps(ops):
     assert rel_l2(x2[:2], x + 0.02 * v) < 1e-6 and torch.equal(x2[:2], x2[2:])
 
 
-@pytest.mark.parametrize("Lc,H", [(77, 16), (96, 12), (33, 4)])
-def test_gemm_cross_attention_epilogue(ops, Lc, H):
+@pytest.mark.parametrize("Lc,H,Bn", [(77, 16, 2), (96, 12, 2), (33, 4, 2), (77, 16, 16), (77, 16, 8)])
+def test_gemm_cross_attention_epilogue(ops, Lc, H, Bn):
     """LN3D_EPI_CROSS_ATTN (query projection + attention over a short cached context in one kernel) vs a torch fp32
-    reference on the same bf16-rounded operands, and vs the unfused HIP path (HEADS GEMM + ln3d_attention_bf16)."""
+    reference on the same bf16-rounded operands, and vs the unfused HIP path (HEADS GEMM + ln3d_attention_bf16).  Bn = 16 is the
+    benchmarked network batch (256x192 tiles, 8 waves); Bn = 8 - the conditional half of it - and Bn = 2 leave that tiling
+    under-filled and take the 128x192 / 4-wave form (2 heads per tile)."""
     torch.manual_seed(0)
     dev = 'cuda'
-    Bn, N, K = 2, 768, 1024
+    N, K = 768, 1024
     M, D = Bn * N, H * 64
     lpad = (Lc + 63) // 64 * 64
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)

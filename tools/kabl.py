@@ -10,6 +10,8 @@ for (M, N, K) in [(12288, 4096, 1024), (12288, 1024, 4096), (12288, 1024, 1024),
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     for abl, nm in NAMES.items():
         os.environ['LN3D_GEMM_ABL'] = str(abl)
+        ops.reload_env()          # the switches are parsed once per process
         us = timeit(lambda: ops.gemm(x, w, None, ops.EPI_BF16, out))
         print(f'M{M} N{N} K{K} ABL={abl} ({nm}): {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s-equiv')
 os.environ.pop('LN3D_GEMM_ABL', None)
+ops.reload_env()
