@@ -116,7 +116,7 @@ def test_unconditional_branch_fold_is_exact_algebra(hip_lib, arch, B, monkeypatc
     print(arch, 'fold vs no fold', e, 'uncond half', rel_l2(y_fold[:B], y_full[:B]), 'cond half', rel_l2(y_fold[B:], y_full[B:]))
     assert e < 1e-3, e                                                # the same arithmetic up to GEMM tile shape / summation order
     if arch != 'DiT-L/2':                                             # oracle forward on the CPU: the smaller cases only
-        y_or = odit.t23d_forward(sd, x2[:2].cpu(), t[:2].cpu(), torch.cat([ctx[:1], ctx[B:B + 1]]).cpu(), heads)
+        y_or = odit.t23d_forward(sd, x2[[0, B]].cpu(), t[:2].cpu(), ctx[[0, B]].cpu(), heads)       # sample 0: its uncond and cond rows
         assert rel_l2(y_fold[[0, B]].cpu(), y_or) < TOL
     # a different prompt in the first half: rows differ inside a sample, nothing is folded, same result as the unfolded path
     ctx2 = torch.cat([synth_input('c', (B, 77, 768), 6).cuda(), c])
