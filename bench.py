@@ -358,7 +358,7 @@ def main():
     lo, hi = parallel.shard_range(Bt, rank, world)
     cams = orbit_cameras(args.views).to(dev)
     if i23d:
-        eng = FlowMatchingEngine(dit, dec)
+        eng = FlowMatchingEngine(dit, dec, sampling_method='euler')             # configs[2]: 50 fixed steps
         c_all = {'crossattn': torch.randn(Bt, 256, 2048, device=dev, generator=g), 'vector': torch.randn(Bt, 768, device=dev, generator=g)}
         c_all['crossattn'][0] = synth_input('ca', (1, 256, 2048), gseed)[0].to(dev)
         c_all['vector'][0] = synth_input('v', (1, 768), gseed)[0].to(dev)

@@ -9,11 +9,13 @@ ONE shared adaLN whose output is added to a per-block learned scale_shift_table,
 tokens, erf-GELU MLP; T2IFinalLayer.  Everything that depends only on the conditioning image (cap_embedder token,
 DINO projection, normed CLIP tokens, every block's cross K / V^T) is computed once per prompt (prepare_context).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops, _cache
-from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
+from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlock, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
                                   self_attention_hip, pad_head_columns, attn_head_pad)
 from .dit_trilatent import DiT, DiT_TriLatent
 
@@ -48,7 +50,12 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         self._pack_embedder(P, device)
         P['t_w0'], P['t_b0'] = bf16(self.t_embedder.mlp[0].weight, device), f32(self.t_embedder.mlp[0].bias, device)
         P['t_w2'], P['t_b2'] = bf16(self.t_embedder.mlp[2].weight, device), f32(self.t_embedder.mlp[2].bias, device)
-        P['ada_w'], P['ada_b'] = bf16(self.adaLN_modulation[1].weight, device), f32(self.adaLN_modulation[1].bias, device)
+        if getattr(self, 'adaLN_modulation', None) is not None:          # PixArt: ONE shared adaLN + per-block tables
+            P['ada_w'], P['ada_b'] = bf16(self.adaLN_modulation[1].weight, device), f32(self.adaLN_modulation[1].bias, device)
+            P['sst'] = f32(torch.stack([b.scale_shift_table.reshape(-1) for b in self.blocks], 0), device)   # [depth, 6D]
+        else:                                                            # plain DiT_I23D: every block's own adaLN, one GEMM
+            P['ada_w'] = bf16(torch.cat([b.adaLN_modulation[1].weight for b in self.blocks], 0), device)    # [depth*6D, D]
+            P['ada_b'] = f32(torch.cat([b.adaLN_modulation[1].bias for b in self.blocks], 0), device)
         if hasattr(self, 'cap_embedder'):
             P['cap_ln_w'], P['cap_ln_b'] = f32(self.cap_embedder[0].weight, device), f32(self.cap_embedder[0].bias, device)
             P['cap_w'], P['cap_b'] = bf16(self.cap_embedder[1].weight, device), f32(self.cap_embedder[1].bias, device)
@@ -58,11 +65,10 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             dp = self._append_proj().y_proj
             P['d_w1'], P['d_b1'] = bf16(dp.fc1.weight, device), f32(dp.fc1.bias, device)
             P['d_w2'], P['d_b2'] = bf16(dp.fc2.weight, device), f32(dp.fc2.bias, device)
-        P['sst'] = f32(torch.stack([b.scale_shift_table.reshape(-1) for b in self.blocks], 0), device)   # [depth, 6D]
         blks = []
         for b in self.blocks:
             q = {}
-            q['n1'], q['n2'] = f32(b.norm1.weight, device), f32(b.norm2.weight, device)
+            q['n1'], q['n2'] = (f32(b.norm1.weight, device), f32(b.norm2.weight, device)) if hasattr(b, 'norm1') else (None, None)
             q['qkv_w'], q['qkv_b'] = bf16(b.attn.qkv.weight, device), f32(b.attn.qkv.bias, device)
             dh = self.embed_dim // self.num_heads
             padw = lambda w: torch.nn.functional.pad(w.detach().float(), (0, attn_head_pad(dh) - dh))     # zero beyond the true head size
@@ -129,6 +135,32 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
                 ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
         return k_all, vt_all, lpad
 
+    def _fold_uc(self, cc, rows):
+        """Samples whose cross-attention context rows are all IDENTICAL - the zero image / text embeddings of the unconditional CFG
+        branch (pipeline._zero_uc; every K / V row of a sample is a row-wise function of its context row, so they are identical
+        too): softmax over identical scores is uniform whatever the query and the cross-attention sub-block is the constant
+        to_out(v) + b per (layer, sample).  For a TRAILING run of such samples (the flow-matching engine's [c, uc] order) the
+        constants are computed here, once per prompt, with the same kernels (bf16 V row -> to_out GEMM, fp32 accumulate); forward()
+        adds them in the gate / residual epilogue of the self-attention projection and runs to_q / attention / to_out on the leading
+        samples only (LN3D_NO_UC_FOLD=1: off).  `rows`: [Bn, L, C] raw context the K / V were made from."""
+        cc['fold'] = 0
+        Bn = cc['Bn']
+        if os.environ.get('LN3D_NO_UC_FOLD') or cc['Lc'] < 1 or Bn < 2:
+            return cc
+        same = (rows == rows[:, :1]).flatten(1).all(1).tolist()              # one host read per prompt
+        fold = 0
+        while fold < Bn and same[Bn - 1 - fold]:
+            fold += 1
+        if not 0 < fold < Bn:
+            return cc
+        P, H, D = self._packed, self.num_heads, self.embed_dim
+        const = torch.zeros(self.depth, Bn, D, dtype=torch.float32, device=rows.device)       # rows < Bn - fold stay 0
+        for i, q in enumerate(P['blocks']):
+            v_row = cc['vt'][i, Bn - fold:, :, :, 0].reshape(fold, H * 64).contiguous()        # V^T[b, h, d, key 0] = the attention output
+            ops.gemm(v_row, q['co_w'], q['co_b'], ops.EPI_F32, const[i, Bn - fold:])
+        cc['fold'], cc['const'] = fold, const
+        return cc
+
     @torch.no_grad()
     def prepare_context(self, context):
         ca, vec = context['crossattn'], context['vector']
@@ -158,7 +190,7 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             ops.gemm(clip_n, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad,
                      heads=H, head_dim=64, transpose_mask=0b10)
             ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
-        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': dino}
+        return self._fold_uc({'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': dino}, ca[..., :C1])
 
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None, **kwargs):
@@ -189,10 +221,8 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         tsum = ws.get('tsum', (Bn, D), torch.float32)                  # t = t_embedder(timesteps) + cap token
         tsilu = ws.get('tsilu', (Bn, D), torch.bfloat16)
         ops.add_act_cast(temb, cc['cls'], tsilu, tsum, Bn * D, 1)
-        t0 = ws.get('t0', (Bn, 6 * D), torch.float32)
-        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, t0)
-        mod = ws.get('modb', (depth, Bn, 6 * D), torch.float32)
-        ops.add_table_rows(t0, P['sst'], mod, depth, Bn, 6 * D)
+        mod_of, ld = self._modulation(tsilu, Bn)
+        nk, neps = self._norm_kind
 
         xt = self._embed_tokens(x, in_scale, Bx, Bn, N)
         ha = ws.get('ha', (Bn, NA, D), torch.bfloat16)
@@ -204,24 +234,27 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         qc = ws.get('qc', (Bn, H, N, 64), torch.bfloat16)
         oc = ws.get('oc', (M, H * 64), torch.bfloat16)
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
-        ld = 6 * D
         probe = getattr(self, '_fc1_probe', None)
-        fuse_cq = ops.heads_norm_fusable(M, H * 64, N, 64)
+        fold = cc.get('fold', 0)                                       # trailing samples with a constant cross-attention output
+        Bc = Bn - fold
+        Mc = Bc * N
+        fuse_cq = ops.heads_norm_fusable(Mc, H * 64, N, 64)
         for i, q in enumerate(P['blocks']):
-            mi = mod[i]
-            ops.norm_modulate(xt, ha, M, D, kind=1, eps=1e-5, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
+            mi = mod_of(i)
+            ops.norm_modulate(xt, ha, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
                               mod_ld=ld, rows_in=N, rows_out=NA)
             ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
-            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld)
+            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld,
+                     res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
             if q['cqn'] is not None and fuse_cq:        # qk_norm of the cross-attention query inside the projection's epilogue
-                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64, head_norm0=q['cqn'])
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=Mc, tokens=N, tok_pad=N, heads=H, head_dim=64, head_norm0=q['cqn'])
             else:
-                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=M, tokens=N, tok_pad=N, heads=H, head_dim=64)
+                ops.gemm(xb, q['cq_w'], None, ops.EPI_HEADS, qc, M=Mc, tokens=N, tok_pad=N, heads=H, head_dim=64)
                 if q['cqn'] is not None:
-                    ops.rmsnorm_heads(qc, q['cqn'], Bn * H * N, 64)
-            ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bn, H, N, N, cc['Lc'], cc['lpad'], 64)
-            ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt)
-            ops.norm_modulate(xt, hb, M, D, kind=1, eps=1e-5, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],
+                    ops.rmsnorm_heads(qc, q['cqn'], Bc * H * N, 64)
+            ops.attention(qc, cc['k'][i], cc['vt'][i], oc, Bc, H, N, N, cc['Lc'], cc['lpad'], 64)
+            ops.gemm(oc, q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt, M=Mc)
+            ops.norm_modulate(xt, hb, M, D, kind=nk, eps=neps, weight=q['n2'], shift=mi[:, 3 * D:], scale=mi[:, 4 * D:],
                               mod_rows=N, mod_ld=ld)
             if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # bench.py measurement hook
@@ -233,6 +266,17 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
                 ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=mi[:, 5 * D:], gate_rows=N, gate_ld=ld)
         return self._output(xt, tsum, Bn, N)
+
+    _norm_kind = (1, 1e-5)             # pre-norms: RMSNorm(eps 1e-5) with a weight; the plain DiT_I23D uses affine-free LayerNorm
+
+    def _modulation(self, tsilu, Bn):
+        """(i -> [Bn, 6D] view of block i's shift/scale/gate rows, row stride): t2i blocks = shared adaLN(t) + scale_shift_table[i]"""
+        P, ws, D, depth = self._packed, self._ws, self.embed_dim, self.depth
+        t0 = ws.get('t0', (Bn, 6 * D), torch.float32)
+        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, t0)
+        mod = ws.get('modb', (depth, Bn, 6 * D), torch.float32)
+        ops.add_table_rows(t0, P['sst'], mod, depth, Bn, 6 * D)
+        return (lambda i: mod[i]), 6 * D
 
     # ---- the two ends of forward that the point-cloud variant replaces
     def _num_tokens(self, x):
@@ -259,6 +303,77 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         eps = self.forward(x, t, context, context_cache=context_cache)
         ops.cfg_combine_dup(eps, float(cfg_scale))
         return eps
+
+
+class DiT_I23D(DiT_I23D_PixelArt):
+    """The plain image-conditioned DiT (reference dit/dit_i23d.py:24-170; registry 'DiT-XL/2', 'DiT-L/2', 'DiT-B/2', 'DiT-B/1' of
+    dit_i23d.DiT_models): ImageCondDiTBlock blocks - every block has its OWN adaLN (no shared adaLN / scale_shift_table),
+    affine-free LayerNorm(eps 1e-6) pre-norms and its own attention_y_norm for the CLIP tokens; the pooled token is
+    clip_text_proj(context['vector']) (CaptionEmbedder, tanh-GELU MLP); T2IFinalLayer.  Runs on the same block machinery as the
+    PixArt variant: only the modulation source, the pre-norm kind and the prompt-side preparation differ."""
+
+    _norm_kind = (0, 1e-6)
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4,
+                 class_dropout_prob=0.1, num_classes=1000, learn_sigma=True, mixing_logit_init=-3, mixed_prediction=True,
+                 context_dim=False, pooling_ctx_dim=768, roll_out=False, vit_blk=ImageCondDiTBlock, final_layer_blk=T2IFinalLayer):
+        DiT_TriLatent.__init__(self, input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio, class_dropout_prob,
+                               num_classes, learn_sigma, mixing_logit_init, mixed_prediction, context_dim, roll_out, vit_blk,
+                               T2IFinalLayer)
+        self.clip_ctx_dim = 1024
+        self.dino_proj = CaptionEmbedder(context_dim, hidden_size)
+        self.clip_spatial_proj = CaptionEmbedder(1024, hidden_size)     # present in the checkpoint, unused by forward
+        self.pooling_ctx_dim = self.clip_text_proj.y_proj.fc1.in_features
+
+    def _modulation(self, tsilu, Bn):
+        P, ws, D, depth = self._packed, self._ws, self.embed_dim, self.depth
+        mod = ws.get('modall', (Bn, depth * 6 * D), torch.float32)
+        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
+        return (lambda i: mod[:, i * 6 * D:]), depth * 6 * D
+
+    def _cls_token(self, vec):
+        """clip_text_proj(context['vector']): Linear -> tanh-GELU -> Linear, fp32 out (dit_i23d.py:112)"""
+        P, ws, D = self._packed, self._ws, self.embed_dim
+        Bn = vec.shape[0]
+        vin = ws.get('cls_in', (Bn, vec.shape[-1]), torch.bfloat16)
+        ops.cast_bf16(vec.contiguous().float(), vin)
+        h1 = ws.get('cls_h', (Bn, D), torch.bfloat16)
+        ops.gemm(vin, P['c_w1'], P['c_b1'], ops.EPI_GELU_TANH, h1)
+        cls = torch.empty(Bn, D, device=vec.device, dtype=torch.float32)
+        ops.gemm(h1, P['c_w2'], P['c_b2'], ops.EPI_F32, cls)
+        return cls
+
+    def _pack_embedder(self, P, device):
+        super()._pack_embedder(P, device)
+        cp = self.clip_text_proj.y_proj
+        P['c_w1'], P['c_b1'] = bf16(cp.fc1.weight, device), f32(cp.fc1.bias, device)
+        P['c_w2'], P['c_b2'] = bf16(cp.fc2.weight, device), f32(cp.fc2.bias, device)
+
+    @torch.no_grad()
+    def prepare_context(self, context):
+        ca, vec = context['crossattn'], context['vector']
+        dev = ca.device
+        self._ensure_packed(dev)
+        P, ws = self._packed, self._ws
+        Bn, Lc, _ = ca.shape
+        D, H, C1 = self.embed_dim, self.num_heads, self.clip_ctx_dim
+        want = C1 + self.dino_proj.y_proj.fc1.in_features
+        if ca.shape[-1] != want or vec.shape[-1] != self.pooling_ctx_dim:
+            raise ValueError(f"context['crossattn'] must be [B, L, {want}] (CLIP {C1} || DINO) and context['vector'] [B, {self.pooling_ctx_dim}]; "
+                             f"got {tuple(ca.shape)} / {tuple(vec.shape)}")
+        cls = self._cls_token(vec)
+        dino = self._appended_tokens(ca[..., C1:])
+        lpad = (Lc + 63) // 64 * 64
+        k_all = torch.zeros(self.depth, Bn, H, lpad, 64, dtype=torch.bfloat16, device=dev)
+        vt_all = torch.zeros(self.depth, Bn, H, 64, lpad, dtype=torch.bfloat16, device=dev)
+        clip = ca[..., :C1].contiguous().float()
+        cn = ws.get('clip_n', (Bn * Lc, C1), torch.bfloat16)
+        for i, q in enumerate(P['blocks']):
+            ops.norm_modulate(clip, cn, Bn * Lc, C1, kind=1, eps=1e-5, weight=q['ynorm'])            # the BLOCK's attention_y_norm
+            ops.gemm(cn, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad, heads=H, head_dim=64,
+                     transpose_mask=0b10)
+            ops.rmsnorm_heads(k_all[i], q['ckn'], Bn * H * lpad, 64)
+        return self._fold_uc({'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': dino}, ca[..., :C1])
 
 
 class DiT_I23D_PixelArt_MVCond(DiT_I23D_PixelArt):
@@ -289,7 +404,7 @@ class DiT_I23D_PixelArt_MVCond(DiT_I23D_PixelArt):
         mvb = ws.get('mv_in', (Bn * Lk, mv.shape[3]), torch.bfloat16)
         ops.cast_bf16(mv.reshape(Bn * Lk, mv.shape[3]).contiguous().float(), mvb)
         k_all, vt_all, lpad = self._cross_kv(mvb, Bn, Lk)
-        return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': appended}
+        return self._fold_uc({'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': cls, 'dino': appended}, mv.reshape(Bn, Lk, -1))
 
 
 class DiT_I23D_PixelArt_MVCond_noClip(DiT_I23D_PixelArt):
@@ -316,8 +431,8 @@ class DiT_I23D_PixelArt_MVCond_noClip(DiT_I23D_PixelArt):
         mvb = self._ws.get('mv_in', (Bn * Lk, mv.shape[3]), torch.bfloat16)
         ops.cast_bf16(mv.reshape(Bn * Lk, mv.shape[3]).contiguous().float(), mvb)
         k_all, vt_all, lpad = self._cross_kv(mvb, Bn, Lk)
-        return {'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': torch.zeros(Bn, D, device=dev),
-                'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
+        return self._fold_uc({'k': k_all, 'vt': vt_all, 'Lc': Lk, 'lpad': lpad, 'Bn': Bn, 'cls': torch.zeros(Bn, D, device=dev),
+                              'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}, mv.reshape(Bn, Lk, -1))
 
 
 class DiT_TriLatent_PixelArt(DiT_I23D_PixelArt):
@@ -365,8 +480,8 @@ class DiT_TriLatent_PixelArt(DiT_I23D_PixelArt):
             ops.norm_modulate(caf, cn, Bn * Lc, Cd, kind=1, eps=1e-5, weight=q['ynorm'])       # the BLOCK's attention_y_norm
             ops.gemm(cn, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad, heads=H, head_dim=64,
                      transpose_mask=0b10)
-        return {'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls,
-                'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}
+        return self._fold_uc({'k': k_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'cls': cls,
+                              'dino': torch.zeros(Bn, 0, D, device=dev, dtype=torch.bfloat16)}, ca)
 
 
 def DiT_L_TriLatent_Pixelart_2(**kwargs):         # dit_trilatent.py:311-318 ('DiT-PixelArt-L/2')
@@ -465,7 +580,24 @@ def DiT_B_Pixelart_2(**kwargs):
     return DiT_I23D_PixelArt(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
 
 
-DiT_models = {'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
+def DiT_XL_2(**kwargs):                   # reference dit_i23d.py:597-626: the plain DiT_I23D sizes
+    return DiT_I23D(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_L_2(**kwargs):
+    return DiT_I23D(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kwargs)
+
+
+def DiT_B_2(**kwargs):
+    return DiT_I23D(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kwargs)
+
+
+def DiT_B_1(**kwargs):
+    return DiT_I23D(depth=12, hidden_size=768, patch_size=1, num_heads=12, **kwargs)
+
+
+DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2, 'DiT-B/1': DiT_B_1,
+              'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
               # reference registry (dit_i23d.py:686-696): 'MV-L/2' is the no-CLIP class, 'MV-B/2' the CLIP+DINO one
               'DiT-PixArt-MV-L/2': DiT_L_Pixelart_MV_2_noclip, 'DiT-PixArt-MV-B/2': DiT_B_Pixelart_MV_2,
               'DiT-PixArt-MVCond-L/2': DiT_L_Pixelart_MV_2, 'DiT-PixArt-MV-XL/2': DiT_XL_Pixelart_MV_2,

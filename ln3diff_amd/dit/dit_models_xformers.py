@@ -149,6 +149,17 @@ class TextCondDiTBlock(DiTBlock):      # dit_models_xformers.py:298-323
         self.cross_attn = MemoryEfficientCrossAttention(query_dim=hidden_size, heads=num_heads)
 
 
+class ImageCondDiTBlock(DiTBlock):                  # dit_models_xformers.py:417-476
+    """Image-conditioned block of the plain DiT_I23D: its OWN adaLN (SiLU -> Linear(D, 6D)), affine-free LayerNorm pre-norms,
+    self-attention over [modulated x ; DINO tokens] with qk-norm, cross-attention (qk-norm) over the CLIP tokens normalised by
+    the block's attention_y_norm (RMSNorm(1024))."""
+
+    def __init__(self, hidden_size, num_heads, context_dim, mlp_ratio=4, **block_kwargs):
+        super().__init__(hidden_size, num_heads, mlp_ratio, context_dim=context_dim, qk_norm=True)
+        self.cross_attn = MemoryEfficientCrossAttention(query_dim=hidden_size, context_dim=context_dim, heads=num_heads, qk_norm=True)
+        self.attention_y_norm = RMSNormP(1024)
+
+
 class ImageCondDiTBlockPixelArtRMSNorm(DiTBlock):   # dit_models_xformers.py:481-539,604-618
     def __init__(self, hidden_size, num_heads, context_dim, mlp_ratio=4, **block_kwargs):
         super().__init__(hidden_size, num_heads, mlp_ratio, context_dim=context_dim, norm_type='rmsnorm', qk_norm=True)

@@ -71,7 +71,7 @@ def create_argparser(objaverse=True):
         trainer_name='sgm_legacy' if objaverse else 'adm', num_samples=4 if objaverse else 10,
         unconditional_guidance_scale=6.5 if objaverse else 1.0, triplane_scaling_divider=0.96806 if objaverse else 1.0,
         timestep_respacing='250' if objaverse else '', diffusion_steps=1000, noise_schedule='linear', sample_steps=250,
-        ode_method='euler', use_ddim=False, clip_denoised=False, image_size=128, num_views=40 if objaverse else 24, export_mesh=False,
+        ode_method='dopri5', use_ddim=False, clip_denoised=False, image_size=128, num_views=40 if objaverse else 24, export_mesh=False,
         mesh_grid=192, mesh_thres=10.0, logdir='./logs/sample', resume_checkpoint='', ddpm_model_path='', rec_model_path='',
         cond_path='', pose_path='', seed=41 if objaverse else 0, context_dim=768, learn_sigma=False, denoise_in_channels=4,
         diffusion_input_size=32, roll_out=True, prompt='' if objaverse else 'a red chair', cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
@@ -304,8 +304,8 @@ def run(args, objaverse=None):
         eng = T23DPipeline(dit, ae, num_steps=args.sample_steps, cfg_scale=args.unconditional_guidance_scale,
                            triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size)
     elif kind == 'flow':
-        # the reference's sample_ode default is torchdiffeq dopri5 (atol 1e-6, rtol 1e-3; transport/transport.py:377); --ode_method
-        # defaults to fixed-step euler here (the benchmark configuration) - pass --ode_method dopri5 for the released behaviour
+        # --ode_method defaults to dopri5 like the reference's sample_ode (torchdiffeq dopri5, atol 1e-6, rtol 1e-3;
+        # transport/transport.py:377); the benchmark configurations ("50 steps") pass --ode_method euler
         eng = FlowMatchingEngine(dit, ae, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
                                  sampling_method=args.ode_method)
     else:

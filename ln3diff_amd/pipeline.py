@@ -179,10 +179,14 @@ class T23DPipeline:
 
 
 class FlowMatchingEngine:
-    """Image -> 3D (and the flow-matching T23D variant): transport ODE sampler over `ddpm_model.forward_with_cfg`."""
+    """Image -> 3D (and the flow-matching T23D variant): transport ODE sampler over `ddpm_model.forward_with_cfg`.
+    `sampling_method` defaults to 'dopri5' like the reference's `sample_ode(num_steps=num_steps, cfg=True)` (transport/transport.py:377:
+    torchdiffeq dopri5, atol 1e-6, rtol 1e-3, output at linspace(0, 1, num_steps)[-1]; restated with torchdiffeq 0.2.3's step
+    controller and dense output in transport/__init__.py - torchdiffeq itself is not installed here).  The benchmark
+    configurations (BASELINE configs[2] / [4]: "50 steps") use the fixed-step 'euler' integrator and say so explicitly."""
 
     def __init__(self, ddpm_model, decoder, conditioner=None, triplane_scaling_divider=TRIPLANE_SCALING_DIVIDER, img_size=128,
-                 path_type='Linear', prediction='velocity', snr_type='lognorm', sampling_method='euler'):
+                 path_type='Linear', prediction='velocity', snr_type='lognorm', sampling_method='dopri5'):
         from .nsr.script_util import AE
         from .transport import Sampler, create_transport
         self.ddpm_model, self.conditioner = ddpm_model, conditioner

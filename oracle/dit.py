@@ -285,6 +285,37 @@ def i23d_forward(sd, x, timesteps, context, num_heads, patch=2, clip_ctx_dim=102
     return unpatchify_trilatent(y, B, patch, c_out).float()
 
 
+def i23d_plain_block(sd, p, x, t_emb, dino_tok, clip_tok, H):
+    """ImageCondDiTBlock.forward (dit/dit_models_xformers.py:450-476): the block's own adaLN, affine-free LayerNorm pre-norms,
+    [modulated x ; DINO] self-attention, cross-attention over the block's attention_y_norm(CLIP tokens)."""
+    N = x.shape[1]
+    mod = linear(F.silu(t_emb), sd[p + 'adaLN_modulation.1.weight'], sd[p + 'adaLN_modulation.1.bias'])
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
+    h = layer_norm(x) * (1 + sc_a[:, None]) + sh_a[:, None]
+    h = torch.cat([h, dino_tok], dim=1)
+    x = x + g_a[:, None] * self_attention(sd, p + 'attn.', h, H)[:, :N]
+    x = x + cross_attention(sd, p + 'cross_attn.', x, rms_norm(clip_tok, sd[p + 'attention_y_norm.weight']), H)
+    h = layer_norm(x) * (1 + sc_m[:, None]) + sh_m[:, None]
+    return x + g_m[:, None] * fused_mlp(sd, p + 'mlp.', h)
+
+
+def i23d_plain_forward(sd, x, timesteps, context, num_heads, patch=2, clip_ctx_dim=1024):
+    """DiT_I23D.forward (dit/dit_i23d.py:96-153): t = t_embedder + clip_text_proj(context['vector']); T2IFinalLayer."""
+    B = x.shape[0]
+    depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    ca = context['crossattn'].float()
+    cls = caption_embedder(sd, 'clip_text_proj.', context['vector'].float())
+    clip_tok, dino_tok = ca[..., :clip_ctx_dim], caption_embedder(sd, 'dino_proj.', ca[..., clip_ctx_dim:])
+    t = t_embedder(sd, timesteps.float()) + cls
+    h = patchify_embed(sd, x, patch) + sd['pos_embed']
+    for i in range(depth):
+        h = i23d_plain_block(sd, f'blocks.{i}.', h, t, dino_tok, clip_tok, num_heads)
+    shift, scale = (sd['final_layer.scale_shift_table'][None] + t[:, None]).chunk(2, dim=1)
+    y = layer_norm(h) * (1 + scale) + shift
+    y = F.linear(y, sd['final_layer.linear.weight'], sd['final_layer.linear.bias'])
+    return unpatchify_trilatent(y, B, patch, y.shape[-1] // (patch * patch)).float()
+
+
 def i23d_mv_forward(sd, x, timesteps, context, num_heads, patch=2):
     """DiT_I23D_PixelArt_MVCond.forward (dit/dit_i23d.py:293-384): multi-view image conditioning.  The projected CLIP spatial
     tokens (clip_spatial_proj) are the ones appended to the self-attention sequence and the flattened multi-view DINO features

@@ -3,7 +3,7 @@
 property tests only.  Produced by the REFERENCE's own Python in the build container (see make_golden.py
 for the rules; the reference does not travel), each section checks oracle/ against it in the same pass.
 
-    python tests/golden/make_golden_geom.py [edm_step1] [flow_step1] [render512] [xl2_edm10] [grid192]
+    python tests/golden/make_golden_geom.py [edm_step1] [flow_step1] [render512] [xl2_edm10] [grid192] [i23d_plain]
 
   edm_step1   DiT-L/2 T23D: ONE EulerEDM + CFG 6.5 step (the first of the 250-step schedule) for 8 different samples, each run by
               the reference at B = 1.  The GPU test runs the 8 samples as ONE batch (network batch 16 x 768 = 12 288 GEMM rows,
@@ -15,6 +15,7 @@ for the rules; the reference does not travel), each section checks oracle/ again
   grid192     the 192^3 sigma / rgb grid of the reference's triplane_decode_grid path (renderer._run_model in 2^16-point chunks,
               vit_triplane.py:2009-2050): every 8th sample per axis (fp16), statistics, and the count of cells above the
               marching-cubes threshold 10 (nsr/train_util_diffusion.py:221-233).
+  i23d_plain  the plain DiT_I23D (ImageCondDiTBlock blocks, dit/dit_i23d.py:24-170), tiny: forward on 2 samples.
 """
 import contextlib
 import io
@@ -184,8 +185,25 @@ def sec_grid192():
          sigma_max=sigma.max(), sigma_min=sigma.min(), sigma_bias=np.array(10.0))
 
 
+def sec_i23d_plain():
+    print('== plain DiT_I23D (ImageCondDiTBlock), tiny and a 72-wide-head case')
+    from dit.dit_i23d import DiT_I23D
+    for tag, hidden, depth, heads, patch in (('tiny', 128, 2, 2, 2), ('h72', 144, 2, 2, 2), ('p1', 128, 1, 2, 1)):
+        with torch.no_grad():
+            m = DiT_I23D(input_size=32, patch_size=patch, in_channels=4, hidden_size=hidden, depth=depth, num_heads=heads, num_classes=0,
+                         learn_sigma=False, context_dim=1024, roll_out=True).eval()
+        sd, shapes = load_synth(m, 0)
+        x = synth_input('x', (2, 12, 32, 32), 9)
+        t = torch.tensor([0.3, 0.8])
+        ctx = {'crossattn': synth_input('ca', (2, 256, 2048), 9), 'vector': synth_input('v', (2, 1024), 9)}
+        y = m(x, t, ctx)
+        y_or = odit.i23d_plain_forward(sd, x, t, ctx, heads, patch)
+        check(f'oracle i23d_plain_forward {tag}', y_or, y, 5e-5)
+        save(f'i23d_plain_{tag}', y=y, t=t, manifest=mg.manifest_json(shapes))
+
+
 SECTIONS = {'edm_step1': sec_edm_step1, 'flow_step1': sec_flow_step1, 'render512': sec_render512, 'xl2_edm10': sec_xl2_edm10,
-            'grid192': sec_grid192}
+            'grid192': sec_grid192, 'i23d_plain': sec_i23d_plain}
 
 if __name__ == '__main__':
     for s in (sys.argv[1:] or list(SECTIONS)):

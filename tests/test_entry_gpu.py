@@ -52,7 +52,7 @@ def test_config4_i23d_512_24cams_mesh_end_to_end(hip_lib, tmp_path):
     """BASELINE configs[4] on one GPU's share at reduced steps: DiT-PixArt-L/2 I23D flow matching, 24 cameras @ 512^2, marching-cubes
     mesh export."""
     args = create_argparser(True).parse_args(("--dit_model_arch DiT-PixArt-L/2 --i23d true --trainer_name flow_matching --num_samples 1 "
-                                              "--sample_steps 4 --unconditional_guidance_scale 4.0 --image_size 512 --num_views 24 "
+                                              "--sample_steps 4 --ode_method euler --unconditional_guidance_scale 4.0 --image_size 512 --num_views 24 "
                                               f"--export_mesh true --mesh_grid 96 --mesh_thres 4.0 --logdir {tmp_path}").split())
     lat = run(args)
     assert lat.shape == (1, 12, 32, 32) and torch.isfinite(lat).all()

@@ -56,7 +56,7 @@ def test_full_flow_pixartl2_euler50_vs_reference_golden(hip_lib):
                                      pooling_ctx_dim=768)
     load_synth(m, 0)
     m = m.cuda()
-    eng = FlowMatchingEngine(m, decoder=_tiny_decoder()[0])
+    eng = FlowMatchingEngine(m, decoder=_tiny_decoder()[0], sampling_method='euler')
     z = synth_input('z', (1, 12, 32, 32), 42).cuda()
     cond = {'crossattn': synth_input('ca', (1, 256, 2048), 42).cuda(), 'vector': synth_input('v', (1, 768), 42).cuda()}
     y = eng.sample(cond, None, batch_size=1, cfg_scale=4.0, num_steps=50, zs=z)

@@ -172,6 +172,87 @@ def test_dopri5_matches_the_oracle_restatement_step_for_step(hip_lib):
     assert float((ya[:1] - exact).abs().max()) < 2e-6, (ya, exact)
 
 
+@pytest.mark.parametrize("size,B", [("tiny", 2), ("tiny", 3), ("L/2", 2)])
+def test_i23d_unconditional_branch_fold_is_exact_algebra(hip_lib, size, B, monkeypatch):
+    """[c, uc] batches of the flow-matching engine: the ZERO conditioning of the unconditional half (pipeline._zero_uc) makes every
+    cross-attention key / value row of those samples identical, so their cross-attention sub-block is the constant to_out(v) + b.
+    prepare_context() folds a TRAILING run of such samples into the self-attention projection's epilogue.  Checked against the same
+    network with the fold off, against the CPU oracle, and that a leading zero half / a non-uniform half is not folded."""
+    from ln3diff_amd.dit.dit_i23d import DiT_models
+    from ln3diff_amd.synth import synth_input
+    from oracle import dit as odit
+    if size == "tiny":
+        m = _build(128, 2, 2)
+    else:
+        m = DiT_models['DiT-PixArt-L/2'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=1024, roll_out=True,
+                                         pooling_ctx_dim=768)
+    sd, _ = load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (B, 12, 32, 32), 7).cuda()
+    x2 = torch.cat([x, x])
+    t = torch.full((2 * B,), 0.37).cuda()
+    ca, v = synth_input('ca', (B, 256, 2048), 7).cuda(), synth_input('v', (B, 768), 7).cuda()
+    ctx = {'crossattn': torch.cat([ca, torch.zeros_like(ca)]), 'vector': torch.cat([v, torch.zeros_like(v)])}      # [c, uc]
+    cc = m.prepare_context(ctx)
+    assert cc['fold'] == B and cc['const'].shape == (m.depth, 2 * B, m.embed_dim) and float(cc['const'][:, :B].abs().max()) == 0.0
+    y_fold = m(x2, t, context_cache=cc)
+    monkeypatch.setenv('LN3D_NO_UC_FOLD', '1')
+    cc0 = m.prepare_context(ctx)
+    assert cc0['fold'] == 0
+    y_full = m(x2, t, context_cache=cc0)
+    monkeypatch.delenv('LN3D_NO_UC_FOLD')
+    e = rel_l2(y_fold, y_full)
+    print(size, B, 'i23d fold vs no fold', e, 'cond half', rel_l2(y_fold[:B], y_full[:B]), 'uncond half', rel_l2(y_fold[B:], y_full[B:]))
+    assert e < 1e-3, e
+    if size == "tiny":
+        pick = [0, B]
+        y_or = odit.i23d_forward(sd, x2[pick].cpu(), t[:2].cpu(), {k: w[pick].cpu() for k, w in ctx.items()}, m.num_heads)
+        assert rel_l2(y_fold[pick].cpu(), y_or) < 2e-2
+    # zeros FIRST ([uc, c]) are not a trailing run; a second half with differing rows is not uniform
+    assert m.prepare_context({'crossattn': torch.cat([torch.zeros_like(ca), ca]), 'vector': torch.cat([torch.zeros_like(v), v])})['fold'] == 0
+    assert m.prepare_context({'crossattn': torch.cat([ca, ca.flip(0)]), 'vector': torch.cat([v, v])})['fold'] == 0
+    # CLIP tokens identical per sample but NON-zero (a constant image embedding): still uniform attention, still exact
+    flat = ca[:, :1].expand(-1, 256, -1).clone()
+    flat[..., 1024:] = ca[..., 1024:]                                  # the DINO half feeds the self-attention tokens, not the keys
+    ctx3 = {'crossattn': torch.cat([ca, flat]), 'vector': torch.cat([v, v])}
+    cc3 = m.prepare_context(ctx3)
+    assert cc3['fold'] == B
+    y3 = m(x2, t, context_cache=cc3)
+    monkeypatch.setenv('LN3D_NO_UC_FOLD', '1')
+    y3_full = m(x2, t, context_cache=m.prepare_context(ctx3))
+    monkeypatch.delenv('LN3D_NO_UC_FOLD')
+    assert rel_l2(y3, y3_full) < 1e-3
+
+
+@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 144, 2, 2, 2), ("p1", 128, 1, 2, 1)])
+def test_i23d_plain_variant_vs_reference_golden(hip_lib, tag, hidden, depth, heads, patch):
+    """The plain DiT_I23D (ImageCondDiTBlock blocks: per-block adaLN, affine-free LayerNorm pre-norms, per-block attention_y_norm,
+    clip_text_proj pooled token; dit/dit_i23d.py:24-170) on the I23D block machinery; h72 = 72-wide heads in padded 128-wide
+    heads (the registry's 'DiT-XL/2'), p1 = patch size 1 ('DiT-B/1': 3072 + 256 tokens)."""
+    from ln3diff_amd.dit.dit_i23d import DiT_I23D
+    from ln3diff_amd.synth import synth_input
+    g = golden('i23d_plain_' + tag)
+    m = DiT_I23D(input_size=32, patch_size=patch, in_channels=4, hidden_size=hidden, depth=depth, num_heads=heads, num_classes=0,
+                 learn_sigma=False, context_dim=1024, roll_out=True)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (2, 12, 32, 32), 9).cuda()
+    ctx = {'crossattn': synth_input('ca', (2, 256, 2048), 9).cuda(), 'vector': synth_input('v', (2, 1024), 9).cuda()}
+    y = m(x, torch.from_numpy(g['t']).cuda(), ctx).cpu()
+    e = rel_l2(y, g['y'])
+    print('plain DiT_I23D', tag, e)
+    assert e < 2e-2, e
+    # its forward_with_cfg (dit_i23d.py:156-170) with the zero unconditional half folded
+    x2 = torch.cat([x, x])
+    t2 = torch.from_numpy(g['t']).cuda().repeat(2)
+    ctx2 = {k: torch.cat([v, torch.zeros_like(v)]) for k, v in ctx.items()}
+    cc = m.prepare_context(ctx2)
+    assert cc['fold'] == 2
+    v = m(x2, t2, context_cache=cc)
+    assert rel_l2(v[:2].cpu(), g['y']) < 2e-2
+
+
 def test_i23d_multiview_variant_vs_reference_golden(hip_lib):
     """DiT_I23D_PixelArt_MVCond (CLIP spatial tokens appended, flattened multi-view DINO features cross-attended, Nk = 1024)."""
     from ln3diff_amd.dit.dit_i23d import DiT_I23D_PixelArt_MVCond

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden, manifest, rel_l2
+from conftest import ROOT, golden, load_synth, manifest, rel_l2
 from ln3diff_amd.synth import synth_input, synth_state_dict, orbit_cameras
 from oracle import dit as odit, samplers as osamp, render as orender, decoder as odec
 
@@ -33,6 +33,9 @@ def test_abi_library_loads_and_exports_header_symbols(hip_lib):
     for s in declared:
         assert hasattr(hip_lib, s), s
     assert declared <= set(_lib.SYMBOLS) | {'ln3d_strerror'}
+    # the ctypes stub of INTEGRATION.md pins the same ABI number the library reports (its argument structs are checked on the GPU)
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert [int(v) for v in re.findall(r'ln3d_abi_version\(\) == (\d+)', doc)] == [hip_lib.ln3d_abi_version()]
 
 
 def test_product_fails_loudly_without_gpu():
@@ -60,6 +63,22 @@ def test_oracle_i23d_tiny_matches_reference_golden():
     ctx = {'crossattn': synth_input('ca', (4, 256, 2048), 0), 'vector': synth_input('v', (4, 768), 0)}
     y = odit.i23d_forward_with_cfg(sd, x, torch.from_numpy(g['t']), ctx, 4.0, 2)
     assert rel_l2(y, g['y']) < 1e-5
+
+
+@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 144, 2, 2, 2), ("p1", 128, 1, 2, 1)])
+def test_oracle_i23d_plain_matches_reference_golden(tag, hidden, depth, heads, patch):
+    """plain DiT_I23D (ImageCondDiTBlock blocks, dit/dit_i23d.py:24-170): the host mirror has the reference's state-dict manifest
+    and the oracle reproduces the reference output."""
+    from ln3diff_amd.dit.dit_i23d import DiT_I23D, DiT_models
+    g = golden('i23d_plain_' + tag)
+    m = DiT_I23D(input_size=32, patch_size=patch, in_channels=4, hidden_size=hidden, depth=depth, num_heads=heads, num_classes=0,
+                 learn_sigma=False, context_dim=1024, roll_out=True)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(g)
+    sd, _ = load_synth(m, 0)
+    ctx = {'crossattn': synth_input('ca', (2, 256, 2048), 9), 'vector': synth_input('v', (2, 1024), 9)}
+    y = odit.i23d_plain_forward(sd, synth_input('x', (2, 12, 32, 32), 9), torch.from_numpy(g['t']), ctx, heads, patch)
+    assert rel_l2(y, g['y']) < 1e-5
+    assert {'DiT-XL/2', 'DiT-L/2', 'DiT-B/2', 'DiT-B/1'} <= set(DiT_models)          # dit_i23d.py:686-690
 
 
 def test_oracle_edm_euler_matches_reference_golden():
