@@ -226,7 +226,9 @@ def load_conditioning(args, dev, objaverse=True):
         return {'crossattn': z.float().cpu(), 'vector': pooled.float().cpu()}, f'FrozenCLIPEmbedder({args.prompt!r})'
     if args.i23d:
         mv = args.mv_input                # MVCond: CLIP spatial tokens [256, 1024] + multi-view DINO tokens; single view: CLIP || DINO
-        c = {'crossattn': synth_input('prompt', (1, 256, 1024 if mv else 2048), args.seed), 'vector': synth_input('vec', (1, 768), args.seed)}
+        # the plain DiT_I23D ('DiT-L/2' ... of the I23D registry) embeds the pooled token with clip_text_proj(context_dim = 1024)
+        vdim = 768 if 'PixArt' in args.dit_model_arch else 1024
+        c = {'crossattn': synth_input('prompt', (1, 256, 1024 if mv else 2048), args.seed), 'vector': synth_input('vec', (1, vdim), args.seed)}
         if mv:
             c['concat'] = synth_input('mv', (1, args.num_mv_views, 256, 1024), args.seed)
         return c, 'synthetic'

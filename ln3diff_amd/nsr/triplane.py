@@ -47,8 +47,20 @@ OBJAVERSE_RENDERING_KWARGS = dict(
 
 class Triplane(nn.Module):
     def __init__(self, c_dim=25, img_resolution=128, img_channels=3, out_chans=96, triplane_size=224,
-                 rendering_kwargs=None, decoder_in_chans=32, decoder_output_dim=3, **_):
+                 rendering_kwargs=None, decoder_in_chans=32, decoder_output_dim=3, sr_kwargs=None, bcg_synthesis_kwargs=None,
+                 lrm_decoder=False, create_triplane=False, **_):
         super().__init__()
+        # The released sampling configurations build the renderer with sr_kwargs={} / no background model / the OSG decoder with
+        # 3 colour channels (nsr/script_util.py:1149,1357-1369): the variants below change what the ray marcher composites (32
+        # feature channels into a super-resolution CNN, nsr/triplane.py:476-500,695-711; a background NeRF; the LRM decoder) and
+        # are not built - they are refused here rather than silently rendering something else.
+        if sr_kwargs or bcg_synthesis_kwargs or lrm_decoder or create_triplane or decoder_output_dim != 3:
+            raise NotImplementedError(
+                "Triplane: sr_kwargs / bcg_synthesis_kwargs / lrm_decoder / create_triplane / decoder_output_dim != 3 are outside the "
+                "sampling hot path (the released samplers use sr_kwargs={}, OSGDecoder with 3 colour channels); got "
+                f"sr_kwargs={sr_kwargs!r}, bcg_synthesis_kwargs={bcg_synthesis_kwargs!r}, lrm_decoder={lrm_decoder}, "
+                f"create_triplane={create_triplane}, decoder_output_dim={decoder_output_dim}")
+        self.superresolution = None                      # attribute of the reference class (nsr/triplane.py:500)
         self.rendering_kwargs = dict(OBJAVERSE_RENDERING_KWARGS if rendering_kwargs is None else rendering_kwargs)
         check_rendering_options(self.rendering_kwargs)
         self.renderer = ImportanceRenderer()             # the explicit-ray seam (nsr/triplane.py:470 in the reference)

@@ -15,7 +15,7 @@ State-dict names follow the reference's released decoder class
 import torch
 import torch.nn.functional as F
 
-from .dit import layer_norm, self_attention, fused_mlp, sincos_pos_embed_2d
+from .dit import OPERAND_ROUND, _r, layer_norm, linear, sdpa, self_attention, fused_mlp, sincos_pos_embed_2d
 
 
 def decoder_pos_embed(D, p=16):
@@ -32,7 +32,7 @@ def patch_embed_triplane(sd, latent, p='superresolution.ldm_upsample.'):
 
 
 def dit2_block(sd, p, x, c, H):
-    mod = F.linear(F.silu(c), sd[p + 'adaLN_modulation.1.weight'], sd[p + 'adaLN_modulation.1.bias'])
+    mod = linear(F.silu(c), sd[p + 'adaLN_modulation.1.weight'], sd[p + 'adaLN_modulation.1.bias'])
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
     x = x + g_a * self_attention(sd, p + 'attn.', layer_norm(x) * (1 + sc_a) + sh_a, H)
     return x + g_m * fused_mlp(sd, p + 'mlp.', layer_norm(x) * (1 + sc_m) + sh_m)
@@ -60,7 +60,8 @@ def _swish(x):
 
 
 def _conv(x, sd, p, pad):
-    return F.conv2d(x, sd[p + 'weight'], sd[p + 'bias'], padding=pad)
+    # under dit.operand_rounding(): bf16 activations / weights into an fp32-accumulating product, like the im2col + MFMA GEMM
+    return F.conv2d(_r(x), _r(sd[p + 'weight']), sd[p + 'bias'], padding=pad)
 
 
 def resnet_block(sd, p, x):
@@ -76,8 +77,11 @@ def attn_block(sd, p, x):
     q, k, v = (_conv(h, sd, p + n, 0) for n in ('q.', 'k.', 'v.'))
     B, C, Hh, Ww = q.shape
     f = lambda t: t.reshape(B, C, Hh * Ww).transpose(1, 2)              # [B,HW,C]
-    s = torch.softmax((f(q) @ f(k).transpose(1, 2)) * (C ** -0.5), dim=-1)
-    o = (s @ f(v)).transpose(1, 2).reshape(B, C, Hh, Ww)
+    if OPERAND_ROUND[0] is None:
+        s = torch.softmax((f(q) @ f(k).transpose(1, 2)) * (C ** -0.5), dim=-1)
+        o = (s @ f(v)).transpose(1, 2).reshape(B, C, Hh, Ww)
+    else:                                                               # q / k / v stored in bf16, one 128-wide head (dit.sdpa's rounding)
+        o = sdpa(_r(f(q))[:, None], _r(f(k))[:, None], _r(f(v))[:, None])[:, 0].transpose(1, 2).reshape(B, C, Hh, Ww)
     return x + _conv(o, sd, p + 'proj_out.', 0)
 
 

@@ -188,7 +188,7 @@ def sec_grid192():
 def sec_i23d_plain():
     print('== plain DiT_I23D (ImageCondDiTBlock), tiny and a 72-wide-head case')
     from dit.dit_i23d import DiT_I23D
-    for tag, hidden, depth, heads, patch in (('tiny', 128, 2, 2, 2), ('h72', 144, 2, 2, 2), ('p1', 128, 1, 2, 1)):
+    for tag, hidden, depth, heads, patch in (('tiny', 128, 2, 2, 2), ('h72', 1152, 1, 16, 2), ('p1', 128, 1, 2, 1)):
         with torch.no_grad():
             m = DiT_I23D(input_size=32, patch_size=patch, in_channels=4, hidden_size=hidden, depth=depth, num_heads=heads, num_classes=0,
                          learn_sigma=False, context_dim=1024, roll_out=True).eval()

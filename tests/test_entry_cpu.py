@@ -28,7 +28,7 @@ def test_reference_launcher_flags_parse():
 
 @pytest.mark.parametrize("flags,msg", [
     (("--dit_model_arch", "DiT-PixArt-L/2"), "I23D architecture"),                       # I23D arch without --i23d
-    (("--i23d", "true", "--dit_model_arch", "DiT-L/2", "--trainer_name", "flow_matching"), "T23D architecture"),
+    (("--i23d", "true", "--dit_model_arch", "DiT-PixelArt-L/2", "--trainer_name", "flow_matching"), "T23D architecture"),
     (("--i23d", "true", "--dit_model_arch", "DiT-PixArt-L/2"), "flow-matching"),         # I23D with the EDM engine
     (("--trainer_name", "no_such"), "known engines"),
     (("--trainer_name", "flow_matching"), "needs an I23D denoiser"),
@@ -41,6 +41,13 @@ def test_unrunnable_flag_combinations_are_refused(flags, msg):
     with pytest.raises(SystemExit) as e:
         validate(_args(True, *flags))
     assert msg in str(e.value)
+
+
+def test_registry_is_chosen_by_the_i23d_flag():
+    """'DiT-L/2' names the text-conditioned DiT_TriLatent without --i23d and the plain image-conditioned DiT_I23D with it, like
+    guided_diffusion/script_util.py picks DiT_models_i23d / DiT_models_t23d."""
+    assert validate(_args(True, "--dit_model_arch", "DiT-L/2")) == 'edm'
+    assert validate(_args(True, "--i23d", "true", "--dit_model_arch", "DiT-L/2", "--trainer_name", "flow_matching")) == 'flow'
 
 
 @pytest.mark.parametrize("flags,msg", [
@@ -117,3 +124,13 @@ def test_bench_refuses_wrong_gpu_counts(argv, env, msg):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300, env=e)
     assert r.returncode != 0 and msg in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])
     assert '"metric"' not in r.stdout
+
+
+def test_renderer_variants_outside_the_hot_path_are_refused():
+    """Triplane(sr_kwargs=..., bcg_synthesis_kwargs=..., lrm_decoder=True, decoder_output_dim=32) change what the ray marcher
+    composites (nsr/triplane.py:476-500): not built, and not silently ignored either."""
+    from ln3diff_amd.nsr.triplane import Triplane
+    assert Triplane(img_resolution=16, sr_kwargs={}, bcg_synthesis_kwargs={}).superresolution is None
+    for kw in (dict(sr_kwargs={'channel_base': 32768}), dict(lrm_decoder=True), dict(decoder_output_dim=32), dict(bcg_synthesis_kwargs={'a': 1})):
+        with pytest.raises(NotImplementedError):
+            Triplane(img_resolution=16, **kw)

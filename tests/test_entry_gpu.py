@@ -17,6 +17,7 @@ SMALL = "--arch_dit_decoder DiT2-B/2 --num_samples 2 --sample_steps 4 --image_si
     (True, "--dit_model_arch DiT-B/2 --trainer_name sgm_legacy --export_mesh true --mesh_thres 4.0"),
     (True, "--dit_model_arch DiT-PixArt-B/2 --i23d true --trainer_name flow_matching --unconditional_guidance_scale 4.0"),
     (True, "--dit_model_arch DiT-PixArt-MV-B/2 --i23d true --trainer_name flow_matching --num_mv_views 2"),
+    (True, "--dit_model_arch DiT-B/2 --i23d true --trainer_name flow_matching --unconditional_guidance_scale 4.0"),      # plain DiT_I23D
     (True, "--dit_model_arch DiT-PixelArt-B/2 --trainer_name flow_matching --unconditional_guidance_scale 4.0"),   # T23D flow matching
     (False, "--dit_model_arch DiT-B/2 --trainer_name adm --timestep_respacing 4"),
     (False, "--dit_model_arch DiT-B/2 --trainer_name vpsde_crossattn --use_ddim true --timestep_respacing ddim4 --unconditional_guidance_scale 3.0"),

@@ -224,7 +224,7 @@ def test_i23d_unconditional_branch_fold_is_exact_algebra(hip_lib, size, B, monke
     assert rel_l2(y3, y3_full) < 1e-3
 
 
-@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 144, 2, 2, 2), ("p1", 128, 1, 2, 1)])
+@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 1152, 1, 16, 2), ("p1", 128, 1, 2, 1)])
 def test_i23d_plain_variant_vs_reference_golden(hip_lib, tag, hidden, depth, heads, patch):
     """The plain DiT_I23D (ImageCondDiTBlock blocks: per-block adaLN, affine-free LayerNorm pre-norms, per-block attention_y_norm,
     clip_text_proj pooled token; dit/dit_i23d.py:24-170) on the I23D block machinery; h72 = 72-wide heads in padded 128-wide

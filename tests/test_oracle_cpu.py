@@ -65,7 +65,7 @@ def test_oracle_i23d_tiny_matches_reference_golden():
     assert rel_l2(y, g['y']) < 1e-5
 
 
-@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 144, 2, 2, 2), ("p1", 128, 1, 2, 1)])
+@pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 1152, 1, 16, 2), ("p1", 128, 1, 2, 1)])
 def test_oracle_i23d_plain_matches_reference_golden(tag, hidden, depth, heads, patch):
     """plain DiT_I23D (ImageCondDiTBlock blocks, dit/dit_i23d.py:24-170): the host mirror has the reference's state-dict manifest
     and the oracle reproduces the reference output."""
