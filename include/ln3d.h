@@ -127,6 +127,12 @@ int ln3d_layernorm_f32(const float* x, const float* w, const float* b, float* y,
 int ln3d_vit_patchify(const float* img, void* out_bf16, int B, int S, int p, int Kpad, void* stream);
 int ln3d_vit_assemble(const float* patch, const float* cls, const float* reg, const float* pos, float* x, int B, int L, int R, int D,
                       void* stream);
+/* kornia.geometry.transform.resize(x, (S, S), 'bicubic', align_corners=True, antialias) -> (x + 1) / 2 -> (x - mean) / std
+ * (the embedders' preprocess(), sgm/modules/encoders/modules.py:633-645,802-814).  x f32 [N, C, H, W] in [-1, 1] -> out f32 [N, C, S, S].
+ * tmp: caller-owned 2 * N*C*H*W floats for the two Gaussian passes (needed only when antialias and a side shrinks);
+ * mean_host / std_host: C floats in HOST memory (read at call time). */
+int ln3d_image_preprocess(const float* x, float* out, float* tmp, int N, int C, int H, int W, int S, int antialias,
+                          const float* mean_host, const float* std_host, void* stream);
 
 /* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
  * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40).

@@ -523,13 +523,178 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalP q) {
     }
   }
 }
+// The projection weight ([p*p*C, D] fp32, 64 KB at D = 1024) staged ONCE per workgroup in LDS, 32 tokens per workgroup: the kernel
+// above re-reads all of it from L2 for every token pair (393 MB per launch at 12288 tokens: 72 us, r3 profile); per-token
+// arithmetic (order of every sum) is unchanged.
+#define FL_WG_TOK 32
+__global__ __launch_bounds__(256) void final_layer_lds_kernel(FinalP q) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int G = q.S / q.p, L = G * G;
+  const int64_t ntok = (int64_t)q.Bn * 3 * L;
+  const int NO = q.p * q.p * q.C;
+  {
+    const float4* src = reinterpret_cast<const float4*>(q.w);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    const int n4 = NO * q.D / 4;
+    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int nv = q.D / 128;
+  for (int it = 0; it < FL_WG_TOK / (4 * FL_TPW); ++it) {
+    const int64_t tok0 = (int64_t)blockIdx.x * FL_WG_TOK + (it * 4 + wid) * FL_TPW;
+    if (tok0 >= ntok) break;
+    float2 v[FL_TPW][MAXV];
+#pragma unroll
+    for (int t = 0; t < FL_TPW; ++t) {
+      const int64_t tok = tok0 + t < ntok ? tok0 + t : ntok - 1;
+      const int b = (int)(tok / (3 * L));
+      const float* xr = q.tokens + tok * q.D;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) { v[t][i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[t][i].x + v[t][i].y; }
+      const float mean = wave_sum_dpp(s) / q.D;
+      float qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) { const float a = v[t][i].x - mean, c = v[t][i].y - mean; qq += a * a + c * c; }
+      const float rstd = rsqrtf(wave_sum_dpp(qq) / q.D + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+          const int d = i * 128 + lane * 2;
+          float2 sc = *reinterpret_cast<const float2*>(q.scale + (int64_t)b * q.mod_ld + d);
+          float2 sh = *reinterpret_cast<const float2*>(q.shift + (int64_t)b * q.mod_ld + d);
+          if (q.scale_table) {
+            const float2 t0 = *reinterpret_cast<const float2*>(q.scale_table + d);
+            const float2 t1 = *reinterpret_cast<const float2*>(q.shift_table + d);
+            sc.x += t0.x; sc.y += t0.y; sh.x += t1.x; sh.y += t1.y;
+          }
+          v[t][i].x = (v[t][i].x - mean) * rstd * (1.f + sc.x) + sh.x;
+          v[t][i].y = (v[t][i].y - mean) * rstd * (1.f + sc.y) + sh.y;
+        }
+    }
+    for (int o = 0; o < NO; ++o) {
+      const float* wr = wl + o * q.D;
+      float acc[FL_TPW];
+#pragma unroll
+      for (int t = 0; t < FL_TPW; ++t) acc[t] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+          const float2 ww = *reinterpret_cast<const float2*>(wr + i * 128 + lane * 2);
+#pragma unroll
+          for (int t = 0; t < FL_TPW; ++t) acc[t] += ww.x * v[t][i].x + ww.y * v[t][i].y;
+        }
+      const int c = o % q.C, ij = o / q.C, i = ij / q.p, j = ij % q.p;
+      const float bo = q.bias[o];
+#pragma unroll
+      for (int t = 0; t < FL_TPW; ++t) {
+        const float a = wave_sum_dpp(acc[t]);
+        const int64_t tok = tok0 + t;
+        if (lane == 0 && tok < ntok) {
+          const int b = (int)(tok / (3 * L)), r = (int)(tok % (3 * L)), n = r / L, l = r % L, ph = l / G, pw = l % G;
+          q.out[(((int64_t)b * q.C * 3 + c * 3 + n) * q.S + q.p * ph + i) * q.S + q.p * pw + j] = a + bo;
+        }
+      }
+    }
+  }
+}
 extern "C" int ln3d_final_layer(const float* tokens, const float* shift, const float* scale, int64_t mod_ld,
                                 const float* shift_table, const float* scale_table, const float* w, const float* bias,
                                 float* out, int Bn, int C, int S, int p, int D, void* stream) {
   if (!tokens || !shift || !scale || !w || !bias || !out || D % 128 || D > 128 * MAXV) return LN3D_ERR_BAD_ARG;
   FinalP q{tokens, shift, scale, mod_ld, shift_table, scale_table, w, bias, out, Bn, C, S, p, D};
   const int64_t ntok = (int64_t)Bn * 3 * (S / p) * (S / p);
+  const size_t wbytes = (size_t)p * p * C * D * 4;
+  if (wbytes <= 80 * 1024 && ntok >= 8 * FL_WG_TOK) {          // weight image in LDS (two workgroups per CU)
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)final_layer_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(final_layer_lds_kernel, dim3((unsigned)((ntok + FL_WG_TOK - 1) / FL_WG_TOK)), dim3(256), wbytes, (hipStream_t)stream, q);
+    return ln3d_check_launch();
+  }
   hipLaunchKernelGGL(final_layer_kernel, dim3((unsigned)((ntok + 4 * FL_TPW - 1) / (4 * FL_TPW))), dim3(256), 0, (hipStream_t)stream, q);
+  return ln3d_check_launch();
+}
+
+// ------------------------------------------------------------------ image preprocessing of the image conditioners
+// kornia.geometry.transform.resize(x, (S, S), 'bicubic', align_corners=True, antialias) -> (x + 1) / 2 -> (x - mean) / std
+// (sgm/modules/encoders/modules.py:633-645,802-814).  kornia as published (geometry/transform/affwarp.py): when a side shrinks,
+// blur with a separable Gaussian (sigma = max((factor - 1) / 2, 0.001), kernel size max(int(4 sigma), 3) made odd, reflect border),
+// then torch's bicubic interpolation (A = -0.75, align_corners, clamped taps: ATen UpSampleBicubic2d).
+struct BlurP { const float* x; float* y; int64_t n; int H, W, k, axis; float w[64]; };
+__global__ void image_blur_kernel(BlurP q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q.n) return;
+  const int x = (int)(i % q.W), y = (int)((i / q.W) % q.H);
+  const int64_t base = i - (int64_t)y * q.W - x;
+  const int r = q.k / 2, L = q.axis ? q.H : q.W, c0 = q.axis ? y : x;
+  float acc = 0.f;
+  for (int t = 0; t < q.k; ++t) {
+    int c = c0 + t - r;
+    c = c < 0 ? -c : c;
+    c = c >= L ? 2 * (L - 1) - c : c;                     // 'reflect' (the border sample is not repeated)
+    acc += q.w[t] * q.x[base + (q.axis ? (int64_t)c * q.W + x : (int64_t)y * q.W + c)];
+  }
+  q.y[i] = acc;
+}
+struct ResizeP { const float* x; float* y; int NC, C, H, W, S; float sy, sx; float mean[4], rstd[4]; };
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+  auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+  w[0] = c2(t + 1.f); w[1] = c1(t); w[2] = c1(1.f - t); w[3] = c2(2.f - t);
+}
+__global__ void image_resize_norm_kernel(ResizeP q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)q.NC * q.S * q.S) return;
+  const int ox = (int)(i % q.S), oy = (int)((i / q.S) % q.S), nc = (int)(i / ((int64_t)q.S * q.S));
+  const float fy = q.sy * oy, fx = q.sx * ox;
+  const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  float wy[4], wx[4];
+  cubic_w(fy - y0, wy); cubic_w(fx - x0, wx);
+  const float* img = q.x + (int64_t)nc * q.H * q.W;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = min(max(y0 - 1 + a, 0), q.H - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) row += wx[b] * img[(int64_t)yy * q.W + min(max(x0 - 1 + b, 0), q.W - 1)];
+    acc += wy[a] * row;
+  }
+  const int c = nc % q.C;
+  q.y[i] = ((acc + 1.0f) * 0.5f - q.mean[c]) * q.rstd[c];
+}
+extern "C" int ln3d_image_preprocess(const float* x, float* out, float* tmp, int N, int C, int H, int W, int S, int antialias,
+                                     const float* mean_host, const float* std_host, void* stream) {
+  if (!x || !out || !mean_host || !std_host || N <= 0 || C <= 0 || C > 4 || H < 2 || W < 2 || S < 2) return LN3D_ERR_BAD_ARG;
+  const float f[2] = {(float)H / S, (float)W / S};
+  const float* src = x;
+  if (antialias && (f[0] > 1.f || f[1] > 1.f) && !(H == S && W == S)) {
+    if (!tmp) return LN3D_ERR_BAD_ARG;
+    const int64_t n = (int64_t)N * C * H * W;
+    for (int axis = 0; axis < 2; ++axis) {              // x pass (factor of W) then y pass, like the two conv2d calls
+      BlurP q;
+      const float sig = fmaxf((f[1 - axis] - 1.0f) / 2.0f, 0.001f);
+      int k = (int)fmaxf(2.0f * 2 * sig, 3.f);
+      k += (k % 2 == 0);
+      if (k > 63) return LN3D_ERR_UNSUPPORTED;
+      float sum = 0.f;
+      for (int t = 0; t < k; ++t) { const float d = (float)(t - k / 2); q.w[t] = expf(-d * d / (2.f * sig * sig)); sum += q.w[t]; }
+      for (int t = 0; t < k; ++t) q.w[t] /= sum;
+      q.x = src; q.y = tmp + (axis ? n : 0); q.n = n; q.H = H; q.W = W; q.k = k; q.axis = axis;
+      hipLaunchKernelGGL(image_blur_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
+      src = q.y;
+    }
+  }
+  ResizeP r;
+  r.x = src; r.y = out; r.NC = N * C; r.C = C; r.H = H; r.W = W; r.S = S;
+  r.sy = S > 1 ? (float)(H - 1) / (float)(S - 1) : 0.f; r.sx = S > 1 ? (float)(W - 1) / (float)(S - 1) : 0.f;
+  for (int c = 0; c < 4; ++c) { r.mean[c] = c < C ? mean_host[c] : 0.f; r.rstd[c] = c < C ? 1.0f / std_host[c] : 1.f; }
+  const int64_t no = (int64_t)N * C * S * S;
+  hipLaunchKernelGGL(image_resize_norm_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
   return ln3d_check_launch();
 }
 

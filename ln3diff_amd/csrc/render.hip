@@ -252,23 +252,28 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   };
   auto reduce = [&](int it, const float4 (&t)[12], const float (&a)[12]) {
     const int src = it * 8 + g;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // explicit packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, r3): a texel's float4 is two even-aligned register pairs and
+    // the tap weight is broadcast by op_sel, so the 48 + 12 + 4 scalar operations of an iteration are 24 + 6 + 2 packed ones; per
+    // channel the evaluation order is the reference's grid_sample order ((nw + ne) + sw) + se, then the plane sum, unchanged
+    ln3d_f32x2 accA = {0.f, 0.f}, accB = {0.f, 0.f};
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      // same evaluation order as the reference's grid_sample: ((nw + ne) + sw) + se per channel
-      float4 s;
-      s.x = t[4 * pl].x * a[4 * pl]; s.y = t[4 * pl].y * a[4 * pl]; s.z = t[4 * pl].z * a[4 * pl]; s.w = t[4 * pl].w * a[4 * pl];
+      const ln3d_f32x2 w0 = {a[4 * pl], a[4 * pl]};
+      ln3d_f32x2 sA = ln3d_f32x2{t[4 * pl].x, t[4 * pl].y} * w0, sB = ln3d_f32x2{t[4 * pl].z, t[4 * pl].w} * w0;
 #pragma unroll
       for (int k = 1; k < 4; ++k) {
-        s.x += t[4 * pl + k].x * a[4 * pl + k]; s.y += t[4 * pl + k].y * a[4 * pl + k];
-        s.z += t[4 * pl + k].z * a[4 * pl + k]; s.w += t[4 * pl + k].w * a[4 * pl + k];
+        const ln3d_f32x2 wk = {a[4 * pl + k], a[4 * pl + k]};
+        sA = __builtin_elementwise_fma(ln3d_f32x2{t[4 * pl + k].x, t[4 * pl + k].y}, wk, sA);
+        sB = __builtin_elementwise_fma(ln3d_f32x2{t[4 * pl + k].z, t[4 * pl + k].w}, wk, sB);
       }
-      acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+      accA += sA; accB += sB;
     }
     // mean over the 3 planes.  torch divides (sum / 3); a multiply by the fp32 reciprocal differs by <= 1 ulp - far inside the
     // renderer's 1e-5 parity - and saves four IEEE division sequences (~40 VALU) per iteration
     const float third = 0.333333343267440796f;
-    acc.x *= third; acc.y *= third; acc.z *= third; acc.w *= third;
+    accA *= third; accB *= third;
+    float4 acc;
+    acc.x = accA.x; acc.y = accA.y; acc.z = accB.x; acc.w = accB.y;
     // feature row of point src: chunks 0-3 = bf16 hi of channels 0-31, chunks 4-7 = bf16 lo; 16-byte chunk c at c ^ ((src >> 1) & 7)
     const uint32_t u0 = __float_as_uint(acc.x) & 0xffff0000u, u1 = __float_as_uint(acc.y) & 0xffff0000u;
     const uint32_t u2 = __float_as_uint(acc.z) & 0xffff0000u, u3 = __float_as_uint(acc.w) & 0xffff0000u;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
     }
 
     // ---- merge coarse + fine by rank (replaces cat + torch.sort + gathers)
-    float* zc_s = feat; float* zf_s = feat + 64; float* srt = feat + 128;   // srt: 128 x {z, sigma, r, g, b}
+    float* zc_s = feat; float* zf_s = feat + 64; float* srt = feat + 128;   // srt: {z, sigma, r, g, b} x 128 ranks
     zc_s[lane] = zc; zf_s[lane] = zf;
     wave_sync();
     // Total order: by depth; equal depths: coarse before fine, then by lane.  The coarse depths are NOT assumed to be sorted by
@@ -545,16 +550,18 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
       rf += (a.x < zf || (a.x == zf && k + 0 < lane)) + (a.y < zf || (a.y == zf && k + 1 < lane)) +
             (a.z < zf || (a.z == zf && k + 2 < lane)) + (a.w < zf || (a.w == zf && k + 3 < lane));
     }
-    srt[rc * 5 + 0] = zc; srt[rc * 5 + 1] = sigc; srt[rc * 5 + 2] = rgbc[0]; srt[rc * 5 + 3] = rgbc[1]; srt[rc * 5 + 4] = rgbc[2];
-    srt[rf * 5 + 0] = zf; srt[rf * 5 + 1] = sigf; srt[rf * 5 + 2] = rgbf[0]; srt[rf * 5 + 3] = rgbf[1]; srt[rf * 5 + 4] = rgbf[2];
+    // five planes of 128 ({z}, {sigma}, {r}, {g}, {b} by rank): lane i then reads its elements 2i, 2i+1 as ONE 8-byte access per plane
+    // and takes element 2i+2 from lane i+1 over DPP (r2's [rank][5] records cost 15 reads with 2-way bank conflicts each)
+    srt[0 * 128 + rc] = zc; srt[1 * 128 + rc] = sigc; srt[2 * 128 + rc] = rgbc[0]; srt[3 * 128 + rc] = rgbc[1]; srt[4 * 128 + rc] = rgbc[2];
+    srt[0 * 128 + rf] = zf; srt[1 * 128 + rf] = sigf; srt[2 * 128 + rf] = rgbf[0]; srt[3 * 128 + rf] = rgbf[1]; srt[4 * 128 + rf] = rgbf[2];
     wave_sync();
-    // lane i: elements 2i, 2i+1, 2i+2 -> intervals 2i and 2i+1 (interval 127 does not exist)
+    // lane i: elements 2i, 2i+1, 2i+2 -> intervals 2i and 2i+1 (interval 127 does not exist: lane 63 repeats element 127)
     float e[3][5];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int idx = 2 * lane + q < 2 * NS ? 2 * lane + q : 2 * NS - 1;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) e[q][c] = srt[idx * 5 + c];
+    for (int c = 0; c < 5; ++c) {
+      const float2 p01 = *reinterpret_cast<const float2*>(srt + c * 128 + 2 * lane);
+      e[0][c] = p01.x; e[1][c] = p01.y;
+      e[2][c] = lane_next(p01.x, p01.y);                  // lane 63 keeps its own element 127
     }
     wave_sync();
     float a0, a1;

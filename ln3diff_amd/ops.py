@@ -240,6 +240,19 @@ def layernorm_f32(x, w, b, y, rows, D, eps=1e-5):
     L.check(L.lib().ln3d_layernorm_f32(_p(x), _p(w), _p(b), _p(y), C.c_int64(rows), D, C.c_float(eps), _stream()), "layernorm_f32")
 
 
+def image_preprocess(x, S, antialias, mean, std):
+    """[N, C, H, W] f32 in [-1, 1] -> resized (kornia bicubic, align_corners, optional antialias blur) and normalised [N, C, S, S]"""
+    _chk_dev(x)
+    N, Cc, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(N, Cc, S, S, device=x.device, dtype=torch.float32)
+    tmp = torch.empty(2 * x.numel(), device=x.device, dtype=torch.float32) if (antialias and (H > S or W > S)) else None
+    m = (C.c_float * Cc)(*[float(v) for v in mean])
+    sd = (C.c_float * Cc)(*[float(v) for v in std])
+    L.check(L.lib().ln3d_image_preprocess(_p(x), _p(out), _p(tmp), N, Cc, H, W, S, int(bool(antialias)), m, sd, _stream()), "image_preprocess")
+    return out
+
+
 def vit_patchify(img, out, B, S, p, Kpad):
     L.check(L.lib().ln3d_vit_patchify(_p(img), _p(out), B, S, p, Kpad, _stream()), "vit_patchify")
 

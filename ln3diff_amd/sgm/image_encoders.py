@@ -170,31 +170,6 @@ class _ViTRunner:
         return y, R
 
 
-def resize_bicubic_antialias(x, size, antialias=True):
-    """Restatement of kornia.geometry.transform.resize(..., interpolation='bicubic', align_corners=True, antialias=...) as published
-    (kornia 0.6 / 0.7, geometry/transform/affwarp.py): when a side shrinks, blur first with a separable Gaussian of
-    sigma = max((factor - 1) / 2, 0.001), kernel size max(int(4 sigma), 3) made odd, reflect border, then F.interpolate bicubic with
-    align_corners=True.  kornia is a third-party dependency absent from this image: PARITY UNPINNED (host-side image plumbing, not
-    part of the timed path; 224 x 224 inputs bypass it)."""
-    import torch.nn.functional as F
-    H, W = x.shape[-2:]
-    fy, fx = H / size[0], W / size[1]
-    if antialias and max(fy, fx) > 1:
-        sig = (max((fy - 1.0) / 2.0, 0.001), max((fx - 1.0) / 2.0, 0.001))
-        ks = [int(max(2.0 * 2 * s, 3)) for s in sig]
-        ks = [k + 1 if k % 2 == 0 else k for k in ks]
-        def g1(k, s):
-            t = torch.arange(k, device=x.device, dtype=x.dtype) - k // 2
-            w = torch.exp(-t * t / (2 * s * s))
-            return w / w.sum()
-        C = x.shape[1]
-        ky, kx = g1(ks[0], sig[0]), g1(ks[1], sig[1])
-        xp = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode='reflect')
-        xp = F.conv2d(xp, kx.view(1, 1, 1, -1).expand(C, 1, 1, -1), groups=C)
-        x = F.conv2d(xp, ky.view(1, 1, -1, 1).expand(C, 1, -1, 1), groups=C)
-    return F.interpolate(x, size=size, mode='bicubic', align_corners=True)
-
-
 class _ImageEmbedderBase(nn.Module):
     MEAN, STD = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
 
@@ -216,10 +191,11 @@ class _ImageEmbedderBase(nn.Module):
         """[-1, 1] images -> the tower's input size -> normalised (sgm/modules/encoders/modules.py:633-645,802-814): kornia
         `geometry.resize(x, (S, S), 'bicubic', align_corners=True, antialias=self.antialias)`, then (x + 1) / 2 and mean / std."""
         S = self._spec_model().image_size
-        if tuple(x.shape[-2:]) != (S, S):
-            x = resize_bicubic_antialias(x, (S, S), antialias=getattr(self, 'antialias', True))
-        x = (x + 1.0) / 2.0
-        return (x - self.mean.to(x)[None, :, None, None]) / self.std.to(x)[None, :, None, None]
+        # one HIP call (ln3d_image_preprocess): Gaussian pre-blur when a side shrinks, bicubic align_corners resize (identity taps
+        # when the input is at size already), (x + 1) / 2, mean / std.  kornia is absent from this image: its published algorithm
+        # is restated (oracle/vit_image.py::resize_bicubic_antialias is the CPU restatement the kernel is tested against) - PARITY
+        # UNPINNED against kornia itself.
+        return ops.image_preprocess(x, S, getattr(self, 'antialias', True), self.MEAN, self.STD)
 
     def _run(self, image):
         if not image.is_cuda:

@@ -73,3 +73,35 @@ def dinov2_forward(sd, img, heads, patch=14, eps=1e-6):
         x = x + g(L + 'ls2.gamma') * F.linear(h, g(L + 'mlp.fc2.weight'), g(L + 'mlp.fc2.bias'))
     x = F.layer_norm(x, (D,), g('norm.weight'), g('norm.bias'), eps)
     return x[:, 0], x[:, 1 + R:]
+
+
+def resize_bicubic_antialias(x, size, antialias=True):
+    """Restatement of kornia.geometry.transform.resize(..., interpolation='bicubic', align_corners=True, antialias=...) as published
+    (kornia 0.6 / 0.7, geometry/transform/affwarp.py): when a side shrinks, blur first with a separable Gaussian of
+    sigma = max((factor - 1) / 2, 0.001), kernel size max(int(4 sigma), 3) made odd, reflect border, then F.interpolate bicubic with
+    align_corners=True.  kornia is a third-party dependency absent from this image: PARITY UNPINNED.  The HIP kernel ln3d_image_preprocess is
+    tested against this function."""
+    H, W = x.shape[-2:]
+    fy, fx = H / size[0], W / size[1]
+    if antialias and max(fy, fx) > 1:
+        sig = (max((fy - 1.0) / 2.0, 0.001), max((fx - 1.0) / 2.0, 0.001))
+        ks = [int(max(2.0 * 2 * s, 3)) for s in sig]
+        ks = [k + 1 if k % 2 == 0 else k for k in ks]
+        def g1(k, s):
+            t = torch.arange(k, device=x.device, dtype=x.dtype) - k // 2
+            w = torch.exp(-t * t / (2 * s * s))
+            return w / w.sum()
+        C = x.shape[1]
+        ky, kx = g1(ks[0], sig[0]), g1(ks[1], sig[1])
+        xp = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode='reflect')
+        xp = F.conv2d(xp, kx.view(1, 1, 1, -1).expand(C, 1, 1, -1), groups=C)
+        x = F.conv2d(xp, ky.view(1, 1, -1, 1).expand(C, 1, -1, 1), groups=C)
+    return F.interpolate(x, size=size, mode='bicubic', align_corners=True)
+
+
+def preprocess(x, S, mean, std, antialias=True):
+    """the embedders' preprocess() (sgm/modules/encoders/modules.py:633-645,802-814)"""
+    if tuple(x.shape[-2:]) != (S, S):
+        x = resize_bicubic_antialias(x, (S, S), antialias)
+    x = (x + 1.0) / 2.0
+    return (x - torch.tensor(mean).to(x)[None, :, None, None]) / torch.tensor(std).to(x)[None, :, None, None]

@@ -351,6 +351,13 @@ def test_timestep_patch_final(ops):
     md = mod.to(dev)
     ops.final_layer(h.to(dev).reshape(-1, D), md[:, :D], md[:, D:], 2 * D, None, None, wf.to(dev), bf_.to(dev), o, 2, 4, 32, 2, D)
     assert rel_l2(o, yr) < 1e-5
+    # few tokens (3 x 16): the kernel without the LDS weight image; same arithmetic
+    h8 = torch.randn(2, 48, D, generator=g)
+    y8 = torch.nn.functional.layer_norm(h8, (D,), eps=1e-6) * (1 + mod[:, None, D:]) + mod[:, None, :D]
+    y8 = odit.unpatchify_trilatent(torch.nn.functional.linear(y8, wf, bf_), 2, 2, 4)            # [2, 12, 8, 8]
+    o8 = torch.empty(2, 12, 8, 8, device=dev)
+    ops.final_layer(h8.to(dev).reshape(-1, D), md[:, :D], md[:, D:], 2 * D, None, None, wf.to(dev), bf_.to(dev), o8, 2, 4, 8, 2, D)
+    assert rel_l2(o8, y8) < 1e-5
 
 
 def test_sampler_steps(ops):

@@ -60,14 +60,34 @@ def test_dinov2_tower_vs_golden(hip_lib, name, B):
 
 
 def test_image_embedder_resizes_other_input_sizes(hip_lib):
-    """preprocess (sgm/modules/encoders/modules.py:633-645): inputs that are not at the tower's size go through the kornia-style
-    bicubic / align_corners / antialias resize (restated, unpinned) instead of being rejected; inputs at size bypass it."""
-    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder, resize_bicubic_antialias
+    """preprocess (sgm/modules/encoders/modules.py:633-645,802-814) is ONE HIP call (ln3d_image_preprocess): kornia-style Gaussian
+    pre-blur when a side shrinks + bicubic / align_corners resize + (x + 1) / 2 + mean / std.  Checked against the CPU restatement
+    of kornia's published algorithm (oracle/vit_image.py; kornia itself is absent: unpinned) for shrinking, growing, anisotropic and
+    at-size inputs, and through an embedder."""
+    from ln3diff_amd import ops
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedder, FrozenOpenCLIPImageEmbedder
+    from oracle import vit_image as ovit
+    g = torch.Generator().manual_seed(3)
+    mean, std = FrozenOpenCLIPImageEmbedder.MEAN, FrozenOpenCLIPImageEmbedder.STD
+    for (H, W, S, aa) in ((64, 64, 56, True), (300, 260, 224, True), (1024, 1024, 224, True), (100, 180, 224, True), (224, 224, 224, True),
+                          (300, 260, 224, False), (57, 56, 56, True)):
+        x = torch.rand(2, 3, H, W, generator=g) * 2 - 1
+        y = ops.image_preprocess(x.cuda(), S, aa, mean, std).cpu()
+        y_or = ovit.preprocess(x, S, mean, std, aa)
+        e = float((y - y_or).abs().max())
+        print('preprocess', (H, W), '->', S, 'antialias', aa, 'max abs diff', e)
+        assert y.shape == (2, 3, S, S) and e < 2e-5, e
+    c = torch.ones(2, 3, 300, 260, device='cuda')                     # a constant image stays constant through blur + bicubic
+    want = torch.tensor([(1.0 - m) / s for m, s in zip(mean, std)])
+    assert float((ops.image_preprocess(c, 224, True, mean, std).cpu() - want[None, :, None, None]).abs().max()) < 1e-5
     m = FrozenDinov2ImageEmbedder(width=128, layers=1, heads=2, image_size=56)
     x = torch.rand(1, 3, 64, 64, device='cuda') * 2 - 1
     a = m(x)
-    b = m(resize_bicubic_antialias(x, (56, 56)))
-    ta, tb = (a if torch.is_tensor(a) else a[0]), (b if torch.is_tensor(b) else b[0])
-    assert torch.equal(ta, tb)
-    c = torch.ones(2, 3, 300, 260, device='cuda')
-    assert float((resize_bicubic_antialias(c, (224, 224)) - 1).abs().max()) < 1e-5
+    ta = a if torch.is_tensor(a) else a[0]
+    assert torch.isfinite(ta).all()
+    # at-size inputs: the bicubic taps are exactly (0, 1, 0, 0) - the same tokens as feeding the normalised image directly
+    x56 = torch.rand(1, 3, 56, 56, device='cuda') * 2 - 1
+    pre = m.preprocess(x56)
+    assert torch.equal(pre, ops.image_preprocess(x56, 56, False, m.MEAN, m.STD))
+    ref = ovit.preprocess(x56.cpu(), 56, m.MEAN, m.STD)
+    assert float((pre.cpu() - ref).abs().max()) < 1e-6

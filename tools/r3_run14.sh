@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+timeout 200 python tools/render_bench.py 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_render_gpu.py tests/test_vit_gpu.py tests/test_kernels_gpu.py tests/test_seams_gpu.py tests/test_geometry_gpu.py tests/test_fullsize_gpu.py -x -q -k "render or rays or 512 or vit or image or embed or final or patch or seams or stub or determin" > gpurun_out/r3_pytest14.log 2>&1; tail -4 gpurun_out/r3_pytest14.log; grep -h "preprocess" gpurun_out/r3_pytest14.log | head -8
+bash tools/r3_prof.sh > gpurun_out/r3_prof14.log 2>&1; head -16 gpurun_out/r3_kernel_stats_t23d.md; head -14 gpurun_out/r3_kernel_stats_i23d.md | tail -11; cut -c1-200 gpurun_out/r3_prof_i23d_bench.json
