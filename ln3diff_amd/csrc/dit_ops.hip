@@ -458,6 +458,8 @@ struct FinalP {
 };
 // One wavefront per 2 tokens (measured 1 / 2 / 4 / 8 tokens: 76 / 63 / 75 / 107 us at 12288 tokens with DPP wave sums): LN + modulate of each token in registers, then every weight row is fetched once per wave
 // (one token per wave re-read the 196 KB projection from L2 for every token); per-token arithmetic order unchanged.
+// r3: staging the projection in LDS once per 32-token workgroup (64 KB -> 2 workgroups = 8 waves per CU) measured SLOWER (116 vs
+// 73 us at 12288 tokens: the kernel lives on wave occupancy, the L2 re-reads of the weight are cheap); not kept.
 #define FL_TPW 2
 __global__ __launch_bounds__(256) void final_layer_kernel(FinalP q) {
   const int lane = threadIdx.x & 63;
@@ -523,97 +525,12 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalP q) {
     }
   }
 }
-// The projection weight ([p*p*C, D] fp32, 64 KB at D = 1024) staged ONCE per workgroup in LDS, 32 tokens per workgroup: the kernel
-// above re-reads all of it from L2 for every token pair (393 MB per launch at 12288 tokens: 72 us, r3 profile); per-token
-// arithmetic (order of every sum) is unchanged.
-#define FL_WG_TOK 32
-__global__ __launch_bounds__(256) void final_layer_lds_kernel(FinalP q) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int G = q.S / q.p, L = G * G;
-  const int64_t ntok = (int64_t)q.Bn * 3 * L;
-  const int NO = q.p * q.p * q.C;
-  {
-    const float4* src = reinterpret_cast<const float4*>(q.w);
-    float4* dst = reinterpret_cast<float4*>(wl);
-    const int n4 = NO * q.D / 4;
-    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
-  const int nv = q.D / 128;
-  for (int it = 0; it < FL_WG_TOK / (4 * FL_TPW); ++it) {
-    const int64_t tok0 = (int64_t)blockIdx.x * FL_WG_TOK + (it * 4 + wid) * FL_TPW;
-    if (tok0 >= ntok) break;
-    float2 v[FL_TPW][MAXV];
-#pragma unroll
-    for (int t = 0; t < FL_TPW; ++t) {
-      const int64_t tok = tok0 + t < ntok ? tok0 + t : ntok - 1;
-      const int b = (int)(tok / (3 * L));
-      const float* xr = q.tokens + tok * q.D;
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i)
-        if (i < nv) { v[t][i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[t][i].x + v[t][i].y; }
-      const float mean = wave_sum_dpp(s) / q.D;
-      float qq = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i)
-        if (i < nv) { const float a = v[t][i].x - mean, c = v[t][i].y - mean; qq += a * a + c * c; }
-      const float rstd = rsqrtf(wave_sum_dpp(qq) / q.D + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-          const int d = i * 128 + lane * 2;
-          float2 sc = *reinterpret_cast<const float2*>(q.scale + (int64_t)b * q.mod_ld + d);
-          float2 sh = *reinterpret_cast<const float2*>(q.shift + (int64_t)b * q.mod_ld + d);
-          if (q.scale_table) {
-            const float2 t0 = *reinterpret_cast<const float2*>(q.scale_table + d);
-            const float2 t1 = *reinterpret_cast<const float2*>(q.shift_table + d);
-            sc.x += t0.x; sc.y += t0.y; sh.x += t1.x; sh.y += t1.y;
-          }
-          v[t][i].x = (v[t][i].x - mean) * rstd * (1.f + sc.x) + sh.x;
-          v[t][i].y = (v[t][i].y - mean) * rstd * (1.f + sc.y) + sh.y;
-        }
-    }
-    for (int o = 0; o < NO; ++o) {
-      const float* wr = wl + o * q.D;
-      float acc[FL_TPW];
-#pragma unroll
-      for (int t = 0; t < FL_TPW; ++t) acc[t] = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-          const float2 ww = *reinterpret_cast<const float2*>(wr + i * 128 + lane * 2);
-#pragma unroll
-          for (int t = 0; t < FL_TPW; ++t) acc[t] += ww.x * v[t][i].x + ww.y * v[t][i].y;
-        }
-      const int c = o % q.C, ij = o / q.C, i = ij / q.p, j = ij % q.p;
-      const float bo = q.bias[o];
-#pragma unroll
-      for (int t = 0; t < FL_TPW; ++t) {
-        const float a = wave_sum_dpp(acc[t]);
-        const int64_t tok = tok0 + t;
-        if (lane == 0 && tok < ntok) {
-          const int b = (int)(tok / (3 * L)), r = (int)(tok % (3 * L)), n = r / L, l = r % L, ph = l / G, pw = l % G;
-          q.out[(((int64_t)b * q.C * 3 + c * 3 + n) * q.S + q.p * ph + i) * q.S + q.p * pw + j] = a + bo;
-        }
-      }
-    }
-  }
-}
 extern "C" int ln3d_final_layer(const float* tokens, const float* shift, const float* scale, int64_t mod_ld,
                                 const float* shift_table, const float* scale_table, const float* w, const float* bias,
                                 float* out, int Bn, int C, int S, int p, int D, void* stream) {
   if (!tokens || !shift || !scale || !w || !bias || !out || D % 128 || D > 128 * MAXV) return LN3D_ERR_BAD_ARG;
   FinalP q{tokens, shift, scale, mod_ld, shift_table, scale_table, w, bias, out, Bn, C, S, p, D};
   const int64_t ntok = (int64_t)Bn * 3 * (S / p) * (S / p);
-  const size_t wbytes = (size_t)p * p * C * D * 4;
-  if (wbytes <= 80 * 1024 && ntok >= 8 * FL_WG_TOK) {          // weight image in LDS (two workgroups per CU)
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)final_layer_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(final_layer_lds_kernel, dim3((unsigned)((ntok + FL_WG_TOK - 1) / FL_WG_TOK)), dim3(256), wbytes, (hipStream_t)stream, q);
-    return ln3d_check_launch();
-  }
   hipLaunchKernelGGL(final_layer_kernel, dim3((unsigned)((ntok + 4 * FL_TPW - 1) / (4 * FL_TPW))), dim3(256), 0, (hipStream_t)stream, q);
   return ln3d_check_launch();
 }

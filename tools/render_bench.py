@@ -11,7 +11,8 @@ if os.environ.get('LN3D_LIB'):
 from ln3diff_amd.nsr.triplane import Triplane          # noqa: E402
 from ln3diff_amd.synth import orbit_cameras            # noqa: E402
 
-dev = 'cuda'
+dev = "cuda"
+torch.manual_seed(0)
 tp = Triplane(img_resolution=256).to(dev)
 tp.decoder.net[2].bias.data[0] += 4.0
 pcl = torch.randn(1, 3, 128, 128, 32, device=dev) * 4
