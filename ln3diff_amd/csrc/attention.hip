@@ -1267,11 +1267,10 @@ template <int DH, int OCC>
 static int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NST = DH == 64 ? 4 : 3;
   constexpr int LDS = NST * (KVB * DH * 2 + DH * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH, OCC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   dim3 grid((p.Nq + 255) / 256, p.B * p.H);
   hipLaunchKernelGGL((attn_kernel<DH, OCC>), grid, dim3(512), LDS, s, p);
@@ -1291,10 +1290,9 @@ static int num_cus_attn() {
 
 static int launch_attn_stream(AttnP p, hipStream_t s) {
   constexpr int LDS = 8 * 16384 + 8 * 4096;     // all 160 KiB of the CU: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   // one workgroup per (batch, head) walks all its query blocks; with fewer heads than CUs the query blocks of a head are
   // shared out so that every CU has work
@@ -1310,10 +1308,9 @@ static int launch_attn_stream(AttnP p, hipStream_t s) {
 template <bool PRIO, bool ST_INORDER>
 static int launch_attn_kres_t(const AttnP& p, hipStream_t s) {
   constexpr int LDS = 768 * 128 + 4 * 8192 + 8 * 4096;   // all 160 KiB of the CU
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kres_kernel<PRIO, ST_INORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   hipLaunchKernelGGL((attn_kres_kernel<PRIO, ST_INORDER>), dim3(p.B * p.H * p.nsplit), dim3(512), LDS, s, p);
   return ln3d_check_launch();

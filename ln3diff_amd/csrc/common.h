@@ -103,6 +103,20 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 // torch.nn.functional.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
+// hipFuncSetAttribute applies to the CURRENT device: remembered per (kernel instantiation, device) so that a process driving several
+// GPUs sets it on each of them (one process per GPU is the deployment, but the library must not depend on it)
+struct AttrOnce {
+  unsigned long long done = 0;
+  bool need() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+  }
+};
+
 static inline int ln3d_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? LN3D_OK : LN3D_ERR_LAUNCH;

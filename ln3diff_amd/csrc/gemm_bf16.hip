@@ -936,11 +936,10 @@ static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
   constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? (NW / WGT) * 96 * 128 : 0);
   static_assert(2 * (BF + BT) * 128 >= NW * 8192 && LDSB <= 163840, "staging regions live in the ring");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-    attr_set = true;
   }
   const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
   hipLaunchKernelGGL((gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>), dim3(nft * ntt), dim3(NW * 64), LDSB, s, p);
@@ -949,11 +948,10 @@ static int launch_ring64(const GemmP& p, hipStream_t s) {
 
 template <int EPI>
 static int launch(const GemmP& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    attr_set = true;
   }
   const int nft = (p.N + BMF - 1) / BMF, ntt = (p.M + BTK - 1) / BTK;
   hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nft * ntt), dim3(256), GEMM_LDS, s, p);

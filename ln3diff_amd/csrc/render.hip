@@ -626,10 +626,9 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   p.coarse_sigma = a->coarse_sigma; p.fine_depths = a->fine_depths;
   p.ray_o = a->ray_o; p.ray_d = a->ray_d; p.fine_sigma = a->fine_sigma; p.coarse_coords = a->coarse_coords; p.fine_coords = a->fine_coords;
   const int64_t nrays = (int64_t)a->V * a->res * a->res;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
-    attr_set = true;
   }
   hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, groups, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
   hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
@@ -669,10 +668,9 @@ extern "C" int ln3d_query_points(const float* planes, int H, int W, const float*
   p.planes = planes; p.H = H; p.W = W; p.coord_scale = (float)(2.0 / (double)box_warp);
   p.bbox_min = -3.0e38f; p.bbox_max = 3.0e38f;
   p.scal_u = reinterpret_cast<uint32_t*>(scalars) + GRP_OFF; p.dec = scalars + DEC_OFF; p.vpc = 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&query_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
-    attr_set = true;
   }
   hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, 0, scalars + DEC_OFF, dec_w0, dec_b0, dec_w1, dec_b1);
   int64_t blocks = ((P + 63) / 64 + 3) / 4;

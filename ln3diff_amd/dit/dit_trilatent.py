@@ -219,17 +219,25 @@ class DiT_TriLatent(DiT):
         ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32_SILU, temb, tsilu)
         ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
 
+    MODCACHE_MAX_BYTES = 4 << 30
+
     def prepare_timesteps(self, t_table):
         """t_table [n_steps, Bn] (the sampler's whole schedule): the timestep-only part of the network (embedder MLP and the
         [24*6+2]*D-wide adaLN projection, 306 MB of weights at DiT-L/2) is evaluated for all steps in ONE pass instead of
-        re-streaming those weights every step.  Returns the cache for forward(..., mod_cache=(cache, step))."""
+        re-streaming those weights every step.  Returns the cache for forward(..., mod_cache=(cache, step)): {'mod': [n * rows,
+        nmod] f32, 'rows': rows}.  When every sample of a step has the same timestep (all samplers of this path) ONE row per step is
+        kept (rows = 1: 150 MB at 250 steps instead of 2.4 GB at network batch 16) and the kernels read it with a sample stride of 0.
+        A schedule whose cache would exceed MODCACHE_MAX_BYTES returns None: the caller runs the modulation GEMMs per step."""
         dev = next(self.parameters()).device
         self._ensure_packed(dev)
         n, Bn = t_table.shape
         nmod = self.depth * 6 * self.embed_dim + 2 * self.embed_dim
-        mod_all = self._ws.get('mod_all', (n * Bn, nmod), torch.float32)
-        self._modulation(t_table.reshape(-1).to(dev), mod_all, 'ma')
-        return mod_all
+        rows = 1 if bool((t_table == t_table[:, :1]).all()) else Bn
+        if n * rows * nmod * 4 > self.MODCACHE_MAX_BYTES:
+            return None
+        mod_all = self._ws.get('mod_all', (n * rows, nmod), torch.float32)
+        self._modulation(t_table[:, :rows].reshape(-1).to(dev), mod_all, 'ma')
+        return {'mod': mod_all, 'rows': rows}
 
     def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None,
                 mod_cache=None, **kwargs):
@@ -253,10 +261,13 @@ class DiT_TriLatent(DiT):
 
         # -- timestep embedding and all adaLN modulations (or the rows prepared for the whole schedule)
         nmod = depth * 6 * D + 2 * D
+        ld = nmod                                              # stride between the samples' modulation rows
         if mod_cache is not None:
-            mod_all, step = mod_cache
-            mod = mod_all[step * Bn:(step + 1) * Bn]
-            assert mod.shape == (Bn, nmod)
+            mc, step = mod_cache
+            rows = mc['rows']
+            assert rows in (1, Bn) and mc['mod'].shape[1] == nmod
+            mod = mc['mod'][step * rows:(step + 1) * rows]
+            ld = nmod if rows == Bn else 0                     # one shared row per step: every sample reads row 0
         else:
             mod = ws.get('mod', (Bn, nmod), torch.float32)
             self._modulation(timesteps, mod, 'm')
@@ -279,10 +290,10 @@ class DiT_TriLatent(DiT):
             o6 = i * 6 * D
             sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
             sh_m, sc_m, g_m = mod[:, o6 + 3 * D:], mod[:, o6 + 4 * D:], mod[:, o6 + 5 * D:]
-            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=nmod)
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=ld)
             ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
             # samples [0, fold) have a constant cross-attention output (prepare_context): it rides on this epilogue as a per-sample row
-            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=nmod,
+            ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=ld,
                      res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
             # cross attention on x (no pre-norm, no gate; reference :318) for the remaining samples
             if fused_cross:     # q projection + attention over the cached text context in ONE kernel (q stays in registers)
@@ -292,7 +303,7 @@ class DiT_TriLatent(DiT):
                 ops.gemm(xb[r0:], q['cq_w'], None, ops.EPI_HEADS, qc, M=M - r0, tokens=N, tok_pad=N, heads=H, head_dim=64)
                 ops.attention(qc, cc['k'][i][fold:], cc['vt'][i][fold:], oc[r0:], Bn - fold, H, N, N, cc['Lc'], cc['lpad'], 64)
             ops.gemm(oc[r0:], q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt[r0:])
-            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=nmod)
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=ld)
             if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
                 # measurement hook (bench.py): HIP events on the launch stream around this one GEMM, inside the real step
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,11 +313,11 @@ class DiT_TriLatent(DiT):
                 probe['events'].append((e0, e1))
             else:
                 ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
-            ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=nmod)
+            ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=ld)
 
         of = depth * 6 * D
         out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)
-        ops.final_layer(xt, mod[:, of:], mod[:, of + D:], nmod, None, None, P['fin_w'], P['fin_b'], out, Bn,
+        ops.final_layer(xt, mod[:, of:], mod[:, of + D:], ld, None, None, P['fin_w'], P['fin_b'], out, Bn,
                         self.out_channels, S, p, D)
         return out
 

@@ -105,8 +105,9 @@ class EulerEDMSampler:
         want_graph = self.use_graph if self.use_graph is not None else bool(os.environ.get('LN3D_GRAPH'))
         if want_graph and mod_all is not None and n > 2:
             x = x.contiguous()
-            mod_step = torch.empty_like(mod_all[:2 * B])
-            mod_step.copy_(mod_all[:2 * B])
+            mrows = mod_all['rows']
+            mod_step = {'mod': torch.empty_like(mod_all['mod'][:mrows]), 'rows': mrows}
+            mod_step['mod'].copy_(mod_all['mod'][:mrows])
             t_dev.fill_(float(quant[0][1]))
             s_dev.fill_(1.0)
             side = torch.cuda.Stream(device=dev)
@@ -123,7 +124,7 @@ class EulerEDMSampler:
             t_dev.fill_(float(idx))
             s_dev.fill_(c_in)
             if graph is not None:
-                mod_step.copy_(mod_all[i * 2 * B:(i + 1) * 2 * B])
+                mod_step['mod'].copy_(mod_all['mod'][i * mrows:(i + 1) * mrows])
                 graph.replay()
                 eps2 = eps_g
             elif mod_all is not None:

@@ -3,7 +3,7 @@
 property tests only.  Produced by the REFERENCE's own Python in the build container (see make_golden.py
 for the rules; the reference does not travel), each section checks oracle/ against it in the same pass.
 
-    python tests/golden/make_golden_geom.py [edm_step1] [flow_step1] [render512] [xl2_edm10] [grid192] [i23d_plain]
+    python tests/golden/make_golden_geom.py [edm_step1] [flow_step1] [render512] [xl2_edm10] [grid192] [i23d_plain] [ddpm250_l2]
 
   edm_step1   DiT-L/2 T23D: ONE EulerEDM + CFG 6.5 step (the first of the 250-step schedule) for 8 different samples, each run by
               the reference at B = 1.  The GPU test runs the 8 samples as ONE batch (network batch 16 x 768 = 12 288 GEMM rows,
@@ -15,6 +15,7 @@ for the rules; the reference does not travel), each section checks oracle/ again
   grid192     the 192^3 sigma / rgb grid of the reference's triplane_decode_grid path (renderer._run_model in 2^16-point chunks,
               vit_triplane.py:2009-2050): every 8th sample per axis (fp16), statistics, and the count of cells above the
               marching-cubes threshold 10 (nsr/train_util_diffusion.py:221-233).
+  ddpm250_l2  DiT-L/2 through SpacedDiffusion('250').p_sample_loop (the north_star's "250-step DDPM"), B = 1: steps 0 / 124 / final.
   i23d_plain  the plain DiT_I23D (ImageCondDiTBlock blocks, dit/dit_i23d.py:24-170), tiny: forward on 2 samples.
 """
 import contextlib
@@ -202,7 +203,39 @@ def sec_i23d_plain():
         save(f'i23d_plain_{tag}', y=y, t=t, manifest=mg.manifest_json(shapes))
 
 
-SECTIONS = {'edm_step1': sec_edm_step1, 'flow_step1': sec_flow_step1, 'render512': sec_render512, 'xl2_edm10': sec_xl2_edm10,
+def sec_ddpm250_l2():
+    print('== DiT-L/2, SpacedDiffusion("250").p_sample_loop (north_star: 250-step DDPM), B = 1')
+    from guided_diffusion import gaussian_diffusion as gd
+    from guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-L/2']
+    m = mg.build_t23d(hidden, depth, heads)
+    sd, _ = load_synth(m, 0)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, '250'), betas=gd.get_named_beta_schedule('linear', 1000),
+                           model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                           loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    tabs = osamp.SpacedTables('250')
+    assert tabs.timestep_map == diff.timestep_map
+    ctx = synth_input('ctx', (1, 77, 768), 1)
+    z = synth_input('z', (1, 12, 32, 32), 1)
+
+    class Adapter:
+        def apply_model_inference(self, x, t, c, **kw):
+            return m(x, t, c)
+    torch.manual_seed(4321)
+    t0 = time.time()
+    y_ref = diff.p_sample_loop(Adapter(), (1, 12, 32, 32), cond=ctx, noise=z.clone(), clip_denoised=False, mixing_normal=False, device='cpu')
+    print(f'  reference loop {time.time() - t0:.0f}s')
+    torch.manual_seed(4321)
+    noises = [torch.randn(1, 12, 32, 32) for _ in range(250)]
+    trace = []
+    t0 = time.time()
+    y_or = osamp.ddpm_p_sample_loop(lambda x, t, c: odit.t23d_forward(sd, x, t, c, heads), z.clone(), noises, ctx, tabs, trace=trace)
+    print(f'  oracle loop {time.time() - t0:.0f}s')
+    check('DDPM-250 DiT-L/2 final latent', y_or, y_ref, 1e-4)
+    save('ddpm250_ditl2', final=y_ref, step0=trace[0], step124=trace[124], noise_seed=np.array(4321))
+
+
+SECTIONS = {'ddpm250_l2': sec_ddpm250_l2, 'edm_step1': sec_edm_step1, 'flow_step1': sec_flow_step1, 'render512': sec_render512, 'xl2_edm10': sec_xl2_edm10,
             'grid192': sec_grid192, 'i23d_plain': sec_i23d_plain}
 
 if __name__ == '__main__':

@@ -125,3 +125,36 @@ def test_unconditional_branch_fold_is_exact_algebra(hip_lib, arch, B, monkeypatc
     # only a LEADING run is folded: zeros in the second half stay on the attention path
     cc3 = m.prepare_context(torch.cat([c, torch.zeros_like(c)]))
     assert cc3['fold'] == 0
+
+
+def test_schedule_modulation_cache_forms(hip_lib):
+    """prepare_timesteps(): the timestep-only sub-network evaluated once for the whole schedule.  One row per step when all samples of
+    a step share the timestep (read with a sample stride of 0), Bn rows per step otherwise, None above the size guard - every form
+    gives the network output of the uncached forward."""
+    from ln3diff_amd.dit.dit_trilatent import DiT_TriLatent
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    from ln3diff_amd.synth import synth_input
+    m = DiT_TriLatent(input_size=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=0, learn_sigma=False,
+                      context_dim=768, roll_out=True, vit_blk=TextCondDiTBlock)
+    load_synth(m, 0)
+    m = m.cuda()
+    Bn = 4
+    x = synth_input('x', (Bn, 12, 32, 32), 2).cuda()
+    ctx = synth_input('c', (Bn, 77, 768), 2).cuda()
+    cc = m.prepare_context(ctx)
+    uniform = torch.tensor([900., 500., 17.])[:, None].expand(3, Bn)
+    mc = m.prepare_timesteps(uniform)
+    assert mc['rows'] == 1 and mc['mod'].shape[0] == 3
+    for step in range(3):
+        want = m(x, uniform[step].cuda(), context_cache=cc).clone()
+        got = m(x, uniform[step].cuda(), context_cache=cc, mod_cache=(mc, step))
+        assert rel_l2(got, want) < 1e-5, step
+    ragged = torch.tensor([[900., 800., 700., 600.], [5., 6., 7., 8.]])
+    mr = m.prepare_timesteps(ragged)
+    assert mr['rows'] == Bn and mr['mod'].shape[0] == 2 * Bn
+    for step in range(2):
+        want = m(x, ragged[step].cuda(), context_cache=cc).clone()
+        got = m(x, ragged[step].cuda(), context_cache=cc, mod_cache=(mr, step))
+        assert rel_l2(got, want) < 1e-5, step
+    m.MODCACHE_MAX_BYTES = 1024
+    assert m.prepare_timesteps(uniform) is None          # the samplers then run the modulation GEMMs per step

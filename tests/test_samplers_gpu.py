@@ -66,6 +66,33 @@ def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
     assert e0 < 2e-3 and e < 1e-2, (e0, e24, e)
 
 
+def test_ddpm250_ditl2_vs_reference_golden(hip_lib):
+    """north_star's "250-step DDPM" at the benchmark's model size: DiT-L/2 through SpacedDiffusion('250').p_sample_loop, B = 1
+    (reference loop on the CPU, tests/golden/make_golden_geom.py ddpm250_l2): steps 0 / 124 / final."""
+    from ln3diff_amd.dit.dit_trilatent import DiT_models
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    from ln3diff_amd.guided_diffusion import gaussian_diffusion as gd
+    from ln3diff_amd.guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    from ln3diff_amd.synth import synth_input
+    g = golden('ddpm250_ditl2')
+    m = DiT_models['DiT-L/2'](input_size=32, num_classes=0, learn_sigma=False, in_channels=4, context_dim=768,
+                              roll_out=True, vit_blk=TextCondDiTBlock)
+    load_synth(m, 0)
+    m = m.cuda()
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, '250'), betas=gd.get_named_beta_schedule('linear', 1000),
+                           model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE)
+    ctx = synth_input('ctx', (1, 77, 768), 1).cuda()
+    z = synth_input('z', (1, 12, 32, 32), 1).cuda()
+    torch.manual_seed(int(g['noise_seed']))
+    noises = [torch.randn(1, 12, 32, 32) for _ in range(250)]      # the reference's randn_like stream
+    tr = []
+    y = diff.p_sample_loop(m, (1, 12, 32, 32), cond=ctx, noise=z, clip_denoised=False, mixing_normal=False,
+                           step_noise=lambda k: noises[k], trace=tr)
+    e0, e124, e = rel_l2(tr[0].cpu(), g['step0']), rel_l2(tr[124].cpu(), g['step124']), rel_l2(y.cpu(), g['final'])
+    print('DDPM-250 DiT-L/2 step0', e0, 'step124', e124, 'final', e)
+    assert e0 < 2e-3 and e < 1e-2, (e0, e124, e)
+
+
 @pytest.mark.parametrize("spec", ['ddim50', 'ddim25'])
 def test_ddim_cfg_vs_reference_golden(hip_lib, spec):
     from ln3diff_amd.guided_diffusion import gaussian_diffusion as gd
