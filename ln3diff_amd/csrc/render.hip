@@ -210,6 +210,16 @@ __device__ __forceinline__ float softplus_log2(float x) {   // log2(1 + 2^x); x 
 __device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, char* wl, const char* cimg,
                                         float px, float py, float pz, int lane, float rgb[3], float& sigma) {
   const int g = lane >> 3, c4 = lane & 7;
+  const bool inb = px >= p.bbox_min && px <= p.bbox_max && py >= p.bbox_min && py <= p.bbox_max && pz >= p.bbox_min &&
+                   pz <= p.bbox_max;
+  const float sg_fill = -3.4028234663852886e38f / 3.0f;   // nan_to_num(-inf) / SAFE_GUARD
+  // r3: a ray that misses the box keeps ALL of its 64 points outside it (its depth range is the call-wide fallback), and every
+  // one of them gets the fill values below whatever the planes hold: skip the gather and the decoder for the whole wave
+  // (wave-uniform branch; 15-40 % of the rays of an orbit view at the reference's camera distance).  Same outputs, bit for bit.
+  if (__builtin_amdgcn_ballot_w64(inb) == 0ull) {
+    sigma = sg_fill; rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;
+    return;
+  }
   const float sx = px * p.coord_scale, sy = py * p.coord_scale, sz = pz * p.coord_scale;
   const int plane_stride = p.H * p.W * 32;
   // ---- bilinear setup, ONCE per point (this lane's own point): per plane 4 clamped tap offsets (bytes, channel 0 of the texel)
@@ -367,9 +377,6 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     o[0] = sx; o[1] = sy; o[2] = sz; o[3] = sx + sy;
   }
   wave_sync();   // the wave's LDS may be overwritten by the caller / next pass
-  const bool inb = px >= p.bbox_min && px <= p.bbox_max && py >= p.bbox_min && py <= p.bbox_max && pz >= p.bbox_min &&
-                   pz <= p.bbox_max;
-  const float sg_fill = -3.4028234663852886e38f / 3.0f;   // nan_to_num(-inf) / SAFE_GUARD
   sigma = inb ? o[0] : sg_fill;
   rgb[0] = inb ? (1.0f / (1.0f + __expf(-o[1]))) * 1.002f - 0.001f : 0.f;
   rgb[1] = inb ? (1.0f / (1.0f + __expf(-o[2]))) * 1.002f - 0.001f : 0.f;
