@@ -225,10 +225,12 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         nk, neps = self._norm_kind
 
         xt = self._embed_tokens(x, in_scale, Bx, Bn, N)
-        ha = ws.get('ha', (Bn, NA, D), torch.bfloat16)
-        if getattr(self, '_ha_src', None) is not cc['dino'] or getattr(self, '_ha_buf', None) is not ha:
-            ha[:, N:].copy_(cc['dino'])                                # appended DINO tokens: constant per prompt, and the
-            self._ha_src, self._ha_buf = cc['dino'], ha                # norm kernel only ever writes rows < N of each sample
+        akv = self._appended_kv(cc, Bn, N) if Ld else None             # per-layer K / V^T of the appended tokens, once per prompt
+        if akv is None:
+            ha = ws.get('ha', (Bn, NA, D), torch.bfloat16)
+            if getattr(self, '_ha_src', None) is not cc['dino'] or getattr(self, '_ha_buf', None) is not ha:
+                ha[:, N:].copy_(cc['dino'])                            # appended DINO tokens: constant per prompt, and the
+                self._ha_src, self._ha_buf = cc['dino'], ha            # norm kernel only ever writes rows < N of each sample
         hb = ws.get('h', (M, D), torch.bfloat16)
         xb = ws.get('xb', (M, D), torch.bfloat16)
         qc = ws.get('qc', (Bn, H, N, 64), torch.bfloat16)
@@ -241,9 +243,20 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
         fuse_cq = ops.heads_norm_fusable(Mc, H * 64, N, 64)
         for i, q in enumerate(P['blocks']):
             mi = mod_of(i)
-            ops.norm_modulate(xt, ha, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
-                              mod_ld=ld, rows_in=N, rows_out=NA)
-            ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
+            if akv is not None:
+                # queries / keys / values of the x tokens only (M rows instead of Bn * NA: the appended quarter of the joint
+                # sequence never changes); their K / V^T rows land in front of the cached ones of this layer
+                sa_k, sa_vt, npad, Dp = akv
+                ops.norm_modulate(xt, hb, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N, mod_ld=ld)
+                qs = ws.get('sa_q', (Bn, H, npad, Dp), torch.bfloat16, zero=True)
+                ao = ws.get('sa_o', (M, H * Dp), torch.bfloat16)
+                ops.gemm(hb, q['qkv_w'], q['qkv_b'], ops.EPI_HEADS, qs, sa_k[i], sa_vt[i], M=M, tokens=N, tok_pad=npad, heads=H,
+                         head_dim=D // H, transpose_mask=0b100, head_dim_pad=Dp, head_norm0=q['qn'], head_norm1=q['kn'])
+                ops.attention(qs, sa_k[i], sa_vt[i], ao, Bn, H, N, npad, NA, npad, Dp, scale=(D // H) ** -0.5)
+            else:
+                ops.norm_modulate(xt, ha, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
+                                  mod_ld=ld, rows_in=N, rows_out=NA)
+                ao = self_attention_hip(ws, 'sa_', ha, Bn, NA, D, H, q['qkv_w'], q['qkv_b'], q['qn'], q['kn'], nq=N)
             ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=mi[:, 2 * D:], gate_rows=N, gate_ld=ld,
                      res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
             if q['cqn'] is not None and fuse_cq:        # qk_norm of the cross-attention query inside the projection's epilogue
@@ -266,6 +279,47 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
                 ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=mi[:, 5 * D:], gate_rows=N, gate_ld=ld)
         return self._output(xt, tsum, Bn, N)
+
+    APPEND_CACHE_MAX_BYTES = 16 << 30
+
+    def _appended_kv(self, cc, Bn, N):
+        """The tokens appended to the self-attention sequence (projected DINO / CLIP tokens) are constant per prompt, and so are
+        their keys and values in every block: self-attention K / V^T buffers per layer ([depth, Bn, H, NA, Dh], 3.2 GB each at
+        network batch 64 - sized for 288 GB of HBM) whose rows [N, NA) are filled ONCE here with the same QKV GEMM + head split
+        (+ fused qk-norm) the blocks use; forward() then projects the x tokens only (25 % fewer QKV GEMM rows per layer and step
+        at 768 + 256 tokens).  Needs the fused qk-norm epilogue (an unfused norm pass would re-normalise the cached rows every
+        step); LN3D_NO_APPEND_CACHE=1 or a cache above APPEND_CACHE_MAX_BYTES fall back to projecting the whole sequence."""
+        if 'akv' in cc:
+            return cc['akv']
+        cc['akv'] = None
+        P, ws, D, H = self._packed, self._ws, self.embed_dim, self.num_heads
+        Ld = cc['dino'].shape[1]
+        Dh = D // H
+        Dp = attn_head_pad(Dh)
+        NA = N + Ld
+        npad = (NA + 63) // 64 * 64
+        qk = P['blocks'][0]['qn'] is not None
+        if (os.environ.get('LN3D_NO_APPEND_CACHE') or N % 32 or Ld % 32
+                or 2 * self.depth * Bn * H * npad * Dp * 2 > self.APPEND_CACHE_MAX_BYTES
+                or (qk and not ops.heads_norm_fusable(Bn * N, 3 * H * Dp, N, Dh, Dp))):
+            return None
+        fused = qk and ops.heads_norm_fusable(Bn * Ld, 3 * H * Dp, Ld, Dh, Dp)    # small prompts batches: norm in a second pass
+        dev = cc['dino'].device
+        sa_k = torch.zeros(self.depth, Bn, H, npad, Dp, dtype=torch.bfloat16, device=dev)
+        sa_vt = torch.zeros(self.depth, Bn, H, Dp, npad, dtype=torch.bfloat16, device=dev)
+        qs = ws.get('sa_q', (Bn, H, npad, Dp), torch.bfloat16, zero=True)
+        rows = cc['dino'].reshape(Bn * Ld, D)
+        for i, q in enumerate(P['blocks']):
+            # outputs 1 / 2 start at token N of every (sample, head): the epilogue addresses [b, h, t, :] / [b, h, :, t] with the
+            # buffers' own tok_pad stride, so a base pointer moved by N tokens is all it takes
+            ops.gemm(rows, q['qkv_w'], q['qkv_b'], ops.EPI_HEADS, qs, sa_k[i][:, :, N:], sa_vt[i][:, :, :, N:], M=Bn * Ld, tokens=Ld,
+                     tok_pad=npad, heads=H, head_dim=Dh, transpose_mask=0b100, head_dim_pad=Dp,
+                     head_norm0=q['qn'] if fused else None, head_norm1=q['kn'] if fused else None)
+            if qk and not fused:       # whole buffer: the x rows are still zero here and stay zero under the norm
+                ops.rmsnorm_heads(sa_k[i], q['kn'], Bn * H * npad, Dp, true_dim=Dh)
+        qs.zero_()                                                      # the scratch queries of the appended rows are not used
+        cc['akv'] = (sa_k, sa_vt, npad, Dp)
+        return cc['akv']
 
     _norm_kind = (1, 1e-5)             # pre-norms: RMSNorm(eps 1e-5) with a weight; the plain DiT_I23D uses affine-free LayerNorm
 

@@ -224,6 +224,44 @@ def test_i23d_unconditional_branch_fold_is_exact_algebra(hip_lib, size, B, monke
     assert rel_l2(y3, y3_full) < 1e-3
 
 
+@pytest.mark.parametrize("which", ["pixart", "mvcond", "plain"])
+def test_appended_token_kv_cache_equals_full_projection(hip_lib, which, monkeypatch):
+    """The tokens appended to the self-attention sequence are constant per prompt: their per-layer K / V^T rows are computed once
+    (DiT_I23D_PixelArt._appended_kv) and the blocks project the x tokens only.  Same network output as projecting the whole
+    [x ; appended] sequence in every block (LN3D_NO_APPEND_CACHE=1), at a width where the fused qk-norm epilogue applies."""
+    from ln3diff_amd.dit import dit_i23d
+    from ln3diff_amd.synth import synth_input
+    kw = dict(input_size=32, patch_size=2, in_channels=4, hidden_size=512, depth=2, num_heads=8, num_classes=0, learn_sigma=False,
+              roll_out=True)
+    B = 6               # 6 x 256 appended rows = 1536: the size from which the appended rows' own projection also takes the fused-norm tiles
+    if which == "pixart":
+        m = dit_i23d.DiT_I23D_PixelArt(context_dim=1024, pooling_ctx_dim=768, **kw)
+        ctx = {'crossattn': synth_input('ca', (B, 256, 2048), 3).cuda(), 'vector': synth_input('v', (B, 768), 3).cuda()}
+    elif which == "mvcond":
+        m = dit_i23d.DiT_I23D_PixelArt_MVCond(context_dim=768, pooling_ctx_dim=768, **kw)
+        ctx = {'crossattn': synth_input('ca', (B, 256, 1024), 3).cuda(), 'vector': synth_input('v', (B, 768), 3).cuda(),
+               'concat': synth_input('mv', (B, 2, 256, 768), 3).cuda()}
+    else:
+        m = dit_i23d.DiT_I23D(context_dim=1024, **kw)
+        ctx = {'crossattn': synth_input('ca', (B, 256, 2048), 3).cuda(), 'vector': synth_input('v', (B, 1024), 3).cuda()}
+    load_synth(m, 0)
+    m = m.cuda()
+    x = synth_input('x', (B, 12, 32, 32), 3).cuda()
+    t = torch.linspace(0.1, 0.9, B).cuda()
+    cc = m.prepare_context(ctx)
+    y = m(x, t, context_cache=cc).clone()
+    assert cc.get('akv') is not None, "the cache did not engage at this width"
+    y2 = m(x, t, context_cache=cc).clone()                 # second evaluation on the same cache (what a sampler step does)
+    assert torch.equal(y, y2)
+    monkeypatch.setenv('LN3D_NO_APPEND_CACHE', '1')
+    cc0 = m.prepare_context(ctx)
+    y0 = m(x, t, context_cache=cc0)
+    assert cc0.get('akv') is None
+    e = rel_l2(y, y0)
+    print(which, 'appended K/V cache vs full projection', e)
+    assert e < 1e-5, e
+
+
 @pytest.mark.parametrize("tag,hidden,depth,heads,patch", [("tiny", 128, 2, 2, 2), ("h72", 1152, 1, 16, 2), ("p1", 128, 1, 2, 1)])
 def test_i23d_plain_variant_vs_reference_golden(hip_lib, tag, hidden, depth, heads, patch):
     """The plain DiT_I23D (ImageCondDiTBlock blocks: per-block adaLN, affine-free LayerNorm pre-norms, per-block attention_y_norm,
