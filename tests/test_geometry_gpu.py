@@ -57,6 +57,20 @@ def test_t23d_bench_geometry_b8_vs_reference_goldens(hip_lib):
     assert e_b['first'] < 1e-3 and e_b['final'] < 1e-2, e_b      # different GEMM tile shapes: summation order only
 
 
+def test_t23d_bench_geometry_is_bitwise_reproducible(hip_lib):
+    """Ten EulerEDM + CFG steps at bench.py's batch (network batch 16 x 768 tokens: the tiles, the K-resident attention kernel, the
+    unconditional-branch fold and the one-row-per-step modulation cache all engaged) twice from the same noise: identical bits."""
+    from ln3diff_amd.sgm.sampling import EulerEDMSampler, DiscreteDenoiser, VanillaCFG
+    from ln3diff_amd.synth import synth_input
+    m = _t23d('DiT-L/2')
+    z = synth_input('z', (8, 12, 32, 32), 77).cuda()
+    cond = {'crossattn': synth_input('c', (8, 77, 768), 77).cuda()}
+    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+    run = lambda: EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z.clone(), cond, uc)
+    a, b = run(), run()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_i23d_bench_geometry_b32_vs_reference_golden(hip_lib):
     from ln3diff_amd.dit.dit_i23d import DiT_models
     from ln3diff_amd.synth import synth_input
@@ -83,6 +97,9 @@ def test_i23d_bench_geometry_b32_vs_reference_golden(hip_lib):
     # the 8 copies of a sample sit in different tiles / workgroups of every kernel: they must agree with each other
     assert max(rel_l2(v[i], v[i % 4]) for i in range(4, B)) < 1e-3
     assert torch.equal(v[:B], v[B:])                              # forward_with_cfg duplicates the guided half (dit_i23d.py:165-167)
+    # run-to-run: the same launch geometry twice (appended-token K / V^T cache rebuilt in between) gives the same bits
+    v2 = m.forward_with_cfg(torch.cat([z, z]), t, context=ctx, cfg_scale=4.0)
+    assert torch.equal(v, v2)
 
 
 def test_xl2_edm10_vs_reference_golden(hip_lib):
