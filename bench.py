@@ -98,6 +98,34 @@ def roofline_probe(dev, n_net, D, iters=20, tokens=768):
             "algorithmic_flop_per_launch": flops}
 
 
+def gate_res_probe(dev, n_net, D, iters=20, tokens=768):
+    """The kernel NAME with the largest share of the step is the gate / residual GEMM (attention projection + MLP fc2 share one
+    instantiation): probe of its bigger member, fc2 (M = n_net * tokens, N = D, K = 4D), fp32 residual stream updated in place."""
+    from ln3diff_amd import ops
+    M, N, K = n_net * tokens, D, 4 * D
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) * 0.02
+    res = torch.randn(M, N, device=dev)
+    gate = torch.randn(n_net, 6 * N, device=dev) * 0.1
+    f = lambda: ops.gemm(x, w, b, ops.EPI_GATE_RES, res, None, gate=gate, gate_rows=tokens, gate_ld=6 * N)
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * N * K
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_bf16_ring64_kernel<GATE_RES, 256x192> (DiT MLP fc2: gate * out + residual into the fp32 stream)", "shape": [M, N, K],
+            "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2),
+            "traffic": None, "traffic_source": "no PMC pass for this kernel (algorithmic bytes: X %d MB + W %d MB read, %d MB residual read + written)"
+            % (M * K * 2 // 2 ** 20, N * K * 2 // 2 ** 20, M * N * 8 // 2 ** 20)}
+
+
 def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     from ln3diff_amd import ops
     Nq = Nq or N
@@ -452,6 +480,7 @@ def main():
                 r["frac"] = round(r["achieved"] / r["peak"], 4)
             rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 1024 if i23d else 768, D // dit.num_heads, Nq=768)
             rec["roofline_raymarch"] = render_probe(dev, dec)
+            rec["roofline_gate_residual"] = gate_res_probe(dev, 2 * B, D, tokens=768)      # last: keeps the other probes comparable with r2 lines
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B, i23d=i23d)
         print(json.dumps(rec), flush=True)
