@@ -59,39 +59,27 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, one v_exp + one v_rcp): the epilogue rounds to bf16 (2^-9)
-// right after, and the libm erff costs ~3x the GEMM's own epilogue budget at K = 1024.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float e = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(e, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-// two elements at a time: the polynomial / scaling parts become v_pk_mul_f32 / v_pk_fma_f32 (one instruction per pair);
-// same A&S 7.1.26 evaluation order per element as gelu_erf
+// Two elements at a time (v_pk_mul_f32 / v_pk_fma_f32: one instruction per pair).  r4: erf(x / sqrt 2) = u P(u^2) with u = x clamped
+// to [-4, 4] and P a degree-7 minimax polynomial constrained to u P(u^2) = 1 at u = 4, so the tails are exact (0 and x) and no
+// transcendental is left: 12 packed + 2 scalar instructions per pair instead of 15 + 2 v_rcp + 6 - the GEMM's GELU epilogue is
+// VALU-throughput bound (19 us of a 108 us fc1 launch at the throttled clock, profiles/r4_gemm.md).  |gelu error| <= 1.4e-4
+// absolute (3.3e-5 |x|), a sixteenth of the bf16 rounding that follows; r3's Abramowitz-Stegun 7.1.28 form was 3e-7.
 typedef float ln3d_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
-  // erf via Abramowitz-Stegun 7.1.28: 1 - (1 + a1 z + ... + a6 z^6)^-16, |err| <= 3e-7 (1.7e-6 in fp32): ONE transcendental
-  // (v_rcp) per element instead of v_rcp + v_exp - the epilogue's GELU is bound by the quarter-rate unit, not by the FMAs
   const ln3d_f32x2 x = {x0, x1};
-  const ln3d_f32x2 z = {fabsf(x0) * 0.70710678118654752f, fabsf(x1) * 0.70710678118654752f};
-  ln3d_f32x2 p = {0.0000430638f, 0.0000430638f};
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{0.0002765672f, 0.0002765672f});
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{0.0001520143f, 0.0001520143f});
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{0.0092705272f, 0.0092705272f});
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{0.0422820123f, 0.0422820123f});
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{0.0705230784f, 0.0705230784f});
-  p = __builtin_elementwise_fma(p, z, ln3d_f32x2{1.0f, 1.0f});
-  p = p * p; p = p * p; p = p * p; p = p * p;
-  const ln3d_f32x2 e = {1.0f - __builtin_amdgcn_rcpf(p.x), 1.0f - __builtin_amdgcn_rcpf(p.y)};
-  const ln3d_f32x2 es = {copysignf(e.x, x0), copysignf(e.y, x1)};
-  const ln3d_f32x2 r = __builtin_elementwise_fma(es, x * 0.5f, x * 0.5f);
+  const ln3d_f32x2 u = {__builtin_amdgcn_fmed3f(x0, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x1, -4.0f, 4.0f)};
+  const ln3d_f32x2 t = u * u;
+  ln3d_f32x2 p = {-2.556055811e-09f, -2.556055811e-09f};
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{2.088922457e-07f, 2.088922457e-07f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{-7.419432677e-06f, -7.419432677e-06f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{1.523832179e-04f, 1.523832179e-04f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{-2.042111475e-03f, -2.042111475e-03f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{1.916284487e-02f, 1.916284487e-02f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{-1.321282834e-01f, -1.321282834e-01f});
+  p = __builtin_elementwise_fma(p, t, ln3d_f32x2{7.976111174e-01f, 7.976111174e-01f});
+  const ln3d_f32x2 e = u * p;                   // erf(x / sqrt 2), +-1 (to fp32 rounding) beyond |x| = 4
+  const ln3d_f32x2 hx = x * 0.5f;
+  const ln3d_f32x2 r = __builtin_elementwise_fma(hx, e, hx);
   x0 = r.x; x1 = r.y;
 }
 __device__ __forceinline__ float gelu_tanh(float x) {

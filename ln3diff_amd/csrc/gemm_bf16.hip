@@ -59,7 +59,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int tok, int fb, float
   } else if constexpr (EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH ||
                        EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU || EPI == LN3D_EPI_CROSS_ATTN) {
     if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
-    if constexpr (EPI == LN3D_EPI_GELU_ERF) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
     if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
     if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
     uint2 o; o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3);
@@ -558,8 +558,39 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
   }
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// LDS-DMA issued as inline asm, not through __builtin_amdgcn_global_load_lds.  r4 finding: hipcc's wait-count pass files the
+// builtin as a FLAT access that touches both VMEM and LDS ("pending flat"), and from the first one on it answers every later
+// LDS dependency with s_waitcnt lgkmcnt(0) instead of a counted wait - the K loop then drains the fragment read it issued one
+// MFMA ago at the head of every K substep, with both waves of a SIMD in the same phase (profiles/r4_gemm_timeline.md).  The asm
+// form is invisible to that pass: fragment reads get counted lgkmcnt(N) waits, and the DMA's own completion is waited for by
+// hand (counted s_waitcnt vmcnt) as before.  M0 = LDS byte address of the wave's 1 KB piece; one wait state between the M0
+// write and the DMA (LDS-DMA reads M0).
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds) {      // wave-uniform base + 32-bit lane offset
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_v(const void* vaddr, uint32_t lds) {                     // per-lane 64-bit address
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
+#ifndef LN3D_RING_D1
+#define LN3D_RING_D1 0       // DMA pieces of a stage issued right behind the barrier (0 = all of them); the rest in the next two substeps
+#endif
+#ifndef LN3D_RING_ABL
+#define LN3D_RING_ABL 0     // bench builds only: 1 = skip the epilogue, 2 = two K stages only, 4 = no DMA in the steady state, 8 = per-stage s_memtime stamps into out2
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // LDS-DMA ring kernel for the large GEMMs: NW waves as (NW/WGT) x WGT, wave tile 32*NI features x 32*NJ tokens.
@@ -607,30 +638,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   }
   const int f0 = ft * BF, t0 = tt * BT;
 
-  // DMA instruction idx = 8 rows x 128 B (W rows first, then X rows) -> LDS bytes [idx*1024, +1024) of the slot
+  // DMA instruction = 8 rows x 128 B -> 1 KB of the slot (W row groups first, then X row groups).  Every wave owns NPWW row
+  // groups of the W tile and NPWX of the X tile, so the operand (and with it the wave-uniform base pointer) of instruction q is
+  // known at compile time: the source is base (SGPR pair) + a 32-bit lane offset - one VGPR per instruction.
+  constexpr int ABL = LN3D_RING_ABL;
+  constexpr int NPWW = BF / 8 / NW, NPWX = BT / 8 / NW;
+  static_assert(BF / 8 % NW == 0 && BT / 8 % NW == 0 && NPWW + NPWX == NPW, "row groups of both operands divide evenly over the waves");
   const int r8 = lane >> 3;
-  // source of DMA instruction q: a wave-uniform base (W or X: SGPR pair) + a 32-bit lane offset - one VGPR per instruction instead
-  // of a 64-bit pointer (the 12-wave tiles run at the 168-register cap: r3 found hipcc spilling 34 registers per K stage there)
-  const char* sbase[NPW]; uint32_t soff[NPW];
+  const char* const Wb = reinterpret_cast<const char*>(p.W + (int64_t)f0 * p.ldw);
+  const char* const Xb = reinterpret_cast<const char*>(p.X + (int64_t)t0 * p.ldx);
+  uint32_t soff[NPW];
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
-    const int idx = wid * NPW + q;
-    const int rt = 8 * (idx < BF / 8 ? idx : idx - BF / 8) + r8;          // row inside its own tile
+    const int rt = 8 * (q < NPWW ? wid * NPWW + q : wid * NPWX + (q - NPWW)) + r8;          // row inside its own tile
     const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
-    if (idx < BF / 8) {
+    if (q < NPWW) {
       int r = f0 + rt; r = r < p.N ? r : p.N - 1;
-      sbase[q] = reinterpret_cast<const char*>(p.W + (int64_t)f0 * p.ldw);
       soff[q] = (uint32_t)(((int64_t)(r - f0) * p.ldw + chunk * 8) * 2);
     } else {
       int r = t0 + rt; r = r < p.M ? r : p.M - 1;
-      sbase[q] = reinterpret_cast<const char*>(p.X + (int64_t)t0 * p.ldx);
       soff[q] = (uint32_t)(((int64_t)(r - t0) * p.ldx + chunk * 8) * 2);
     }
   }
-  const int dst0 = wid * NPW * 1024;
-#define Y_ISSUE1(s, q)                                                                                       \
-  __builtin_amdgcn_global_load_lds((glb_void_t*)(sbase[q] + (s) * 128 + soff[q]),                             \
-      (lds_void_t*)(smem + ((s) & 1) * STAGEB + dst0 + (q) * 1024), 16, 0, 0)
+  const int dW0 = wid * NPWW * 1024, dX0 = WB + wid * NPWX * 1024;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+#define Y_ISSUE1(s, q)                                                                                        \
+  lds_dma16_s(((q) < NPWW ? Wb : Xb) + (int64_t)(s) * 128, soff[q],                                           \
+              lds0 + ((s) & 1) * STAGEB + ((q) < NPWW ? dW0 + (q) * 1024 : dX0 + ((q) - NPWW) * 1024))
 
   const int key = (l31 >> 1) & 7;
   const int a_row = (wf * 32 * NI + l31) * 128;
@@ -647,7 +681,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
-  const int ns = (p.abl & 2) ? 2 : p.K / 64;
+  const int ns = (ABL & 2) ? 2 : p.K / 64;
 
   // CROSS_ATTN: the K rows of this tile's sample and 4 heads go into the LDS above the ring now (40 KB at 77 keys), long
   // before the epilogue needs them.  Row r of head hh at XK + hh*XKH + r*128, 16-byte chunk c at c ^ ((r >> 1) & 7).
@@ -661,15 +695,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
       const int hh = idx / nrows8, j = idx - hh * nrows8;
       const int r = 8 * j + (lane >> 3);
       const bf16_t* src_k = kc + ((int64_t)hh * p.ctx_pad + r) * 64 + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src_k, (lds_void_t*)(smem + XK + hh * XKH + j * 1024), 16, 0, 0);
+      lds_dma16_v(src_k, lds0 + XK + hh * XKH + j * 1024);
     }
   }
 
 #pragma unroll
   for (int q = 0; q < NPW; ++q) Y_ISSUE1(0, q);
-  if (ns > 1) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) Y_ISSUE1(1, q); }
-  if (ns > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); }
-  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  if (ns > 1) {
+    _Pragma("unroll") for (int q = 0; q < NPW; ++q) Y_ISSUE1(1, q);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+  } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < NI; ++i) a0[i] = Y_RDA(0, 0, i);
@@ -677,46 +712,81 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   for (int j = 0; j < NJ; ++j) b0[j] = Y_RDB(0, 0, j);
 
 #define Y_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
-  // substep: multiply (CA, CB) while (s2, ks2) is read into (NA, NB)
-#define Y_PHASE(CA, CB, NA, NB, s2, ks2, RD)                                                              \
+  // D1 of a stage's NPW DMA instructions are issued in the last substep of stage s (right behind the barrier that retires
+  // their slot), the other NPW - D1 in the first two substeps of stage s+1 (LATE slots apart): the texture path accepts a
+  // 1 KB piece every ~16 cycles and a wave that finds its queue full stalls with its MFMAs behind it.
+  constexpr int D1 = (LN3D_RING_D1 > 0 && LN3D_RING_D1 < NPW) ? LN3D_RING_D1 : NPW;
+  constexpr int NLATE = NPW - D1;
+  // substep: multiply (CA, CB) while (s2, ks2) is read into (NA, NB); LATE0 >= 0: late DMA pieces [LATE0, LATE1) of stage sd
+#define Y_PHASE(CA, CB, NA, NB, s2, ks2, LATE, sd, L0, L1)                                                \
   _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                        \
     Y_MMA(CA, CB, n);                                                                                     \
-    if (RD) {                                                                                             \
-      if (n < NI) NA[n] = Y_RDA(s2, ks2, n);                                                              \
-      else if (n < NR) NB[n - NI] = Y_RDB(s2, ks2, n - NI);                                               \
+    if (n < NI) NA[n] = Y_RDA(s2, ks2, n);                                                                \
+    else if (n < NR) NB[n - NI] = Y_RDB(s2, ks2, n - NI);                                                 \
+    if (LATE) {                                                                                           \
+      _Pragma("unroll") for (int d = (L0); d < (L1); ++d)                                                 \
+          if ((d - (L0)) * NM / ((L1) - (L0) > 0 ? (L1) - (L0) : 1) == n) Y_ISSUE1(sd, d);                \
     }                                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
   }
-#define Y_STAGE(s, FILL, MORE)                                                                            \
+  // The stage's one barrier sits behind the FIRST MFMA of the last substep: every wave has read the last fragments of slot
+  // s & 1 (lgkmcnt(0): they were issued at least two MFMAs earlier) and its own DMAs of stage s+1 have landed (vmcnt(0): the
+  // only ones in flight); the fragment reads of stage s+1 and the first D1 DMAs of stage s+2 fill the remaining NM-1 slots.
+#define Y_SYNC(s)                                                                                         \
   {                                                                                                       \
-    Y_PHASE(a0, b0, a1, b1, s, 1, true);                                                                  \
-    Y_PHASE(a1, b1, a0, b0, s, 2, true);                                                                  \
-    Y_PHASE(a0, b0, a1, b1, s, 3, true);                                                                  \
-    if (MORE) {                                                                                           \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* stage s+1 (the only DMAs in flight) landed */  \
-      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                 \
-      __builtin_amdgcn_s_barrier();                                                                       \
+    uint64_t tA_ = 0, tB_ = 0;                                                                            \
+    if constexpr ((ABL & 8) != 0) tA_ = __builtin_amdgcn_s_memtime();                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                   \
+    if constexpr ((ABL & 8) != 0) tB_ = __builtin_amdgcn_s_memtime();                                     \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    if constexpr ((ABL & 8) != 0) {       /* bench builds: per-wave stamps (before the waits, before / behind the barrier) -> out2 */ \
+      const uint64_t tC_ = __builtin_amdgcn_s_memtime();                                                  \
+      if (lane == 0 && (s) < 64) {                                                                        \
+        uint32_t* tl_ = (uint32_t*)p.out2 + (((int64_t)blockIdx.x * NW + wid) * 64 + (s)) * 4;            \
+        tl_[0] = (uint32_t)tA_; tl_[1] = (uint32_t)tB_; tl_[2] = (uint32_t)tC_;                           \
+      }                                                                                                   \
     }                                                                                                     \
+  }
+  static_assert(NM - 1 >= NR, "one fragment read per MFMA slot behind the barrier");
+  constexpr int LH = D1 + (NLATE + 1) / 2;             // late pieces [D1, LH) in the first substep, [LH, NPW) in the second
+#define Y_STAGE(s, PREV, FILL, MORE)                                                                      \
+  {                                                                                                       \
+    Y_PHASE(a0, b0, a1, b1, s, 1, (PREV) && NLATE > 0, (s) + 1, D1, LH);                                  \
+    Y_PHASE(a1, b1, a0, b0, s, 2, (PREV) && NLATE > 0, (s) + 1, LH, NPW);                                 \
+    Y_PHASE(a0, b0, a1, b1, s, 3, false, 0, 0, 0);                                                        \
     _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
       Y_MMA(a1, b1, n);                                                                                   \
+      if (MORE && n == 0) Y_SYNC(s);                                                                      \
       if (MORE) {                                                                                         \
-        if (n < NI) a0[n] = Y_RDA((s) + 1, 0, n);                                                         \
-        else if (n < NR) b0[n - NI] = Y_RDB((s) + 1, 0, n - NI);                                          \
+        if (n >= 1 && n - 1 < NI) a0[n - 1] = Y_RDA((s) + 1, 0, n - 1);                                   \
+        else if (n >= 1 && n - 1 < NR) b0[n - 1 - NI] = Y_RDB((s) + 1, 0, n - 1 - NI);                    \
       }                                                                                                   \
       if (FILL) {                                                                                         \
-        _Pragma("unroll") for (int d = 0; d < NPW; ++d)                                                   \
-            if (d * NM / NPW == n) Y_ISSUE1((s) + 2, d);                                                  \
+        _Pragma("unroll") for (int d = 0; d < D1; ++d)                                                    \
+            if (1 + d * (NM - 1) / D1 == n) Y_ISSUE1((s) + 2, d);                                         \
       }                                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
     }                                                                                                     \
   }
+  // Nothing but LDS reads may be pending when the K loop is entered: a kernel-argument s_load still counted on lgkmcnt makes
+  // hipcc answer the loop head's fragment dependency with lgkmcnt(0) on EVERY iteration (mixed event types cannot be counted).
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   int s = 0;
-  if (p.abl & 4) { for (; s + 2 < ns; ++s) Y_STAGE(s, false, true); }
-  for (; s + 2 < ns; ++s) Y_STAGE(s, true, true);
-  if (ns >= 2) { Y_STAGE(s, false, true); ++s; }
-  Y_STAGE(s, false, false);
+  if constexpr ((ABL & 4) != 0) {                        // bench builds: no DMA in the steady state
+    for (; s + 1 < ns; ++s) Y_STAGE(s, false, false, true);
+  } else if (ns >= 3) {
+    Y_STAGE(0, false, true, true);
+    for (s = 1; s + 2 < ns; ++s) Y_STAGE(s, true, true, true);
+    Y_STAGE(s, true, false, true);
+    ++s;
+  } else if (ns == 2) {
+    Y_STAGE(0, false, false, true);
+    s = 1;
+  }
+  Y_STAGE(s, false, false, false);
 
-  if ((p.abl & 1) && acc[0][0][0] != 12345.f) return;
+  if constexpr ((ABL & 1) != 0) { if (acc[0][0][0] != 12345.f) return; }
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) {
     // acc[i][j] = q^T of head (f0/64 + wf): features (rows) x the wave's 96 tokens (columns, lane & 31 within block j).
     // Same swapped products and lane-local softmax as csrc/attention.hip; q is consumed straight from the accumulators
@@ -731,7 +801,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
         const int hh = idx / (nkb * 8), rem = idx - hh * nkb * 8, kb = rem >> 3, j = rem & 7;
         const int vrow = 8 * j + (lane >> 3);
         const bf16_t* src_v = vc + ((int64_t)hh * 64 + vrow) * p.ctx_pad + kb * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src_v, (lds_void_t*)(smem + (hh * 2 + kb) * 8192 + j * 1024), 16, 0, 0);
+        lds_dma16_v(src_v, lds0 + (hh * 2 + kb) * 8192 + j * 1024);
       }
     }
     const int kkey = (l31 >> 1) & 7;
@@ -931,6 +1001,323 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   staged_epilogue<EPI, NI, NJ, (NW <= 8)>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent ring kernel for the bf16-output GEMMs with several tiles per CU (fc1 + GELU, QKV + head split, plain bf16): one
+// 8-wave workgroup per CU walks its tiles (256 features x 192 tokens, wave tile 64 x 96 like configuration 9) and the STORES of
+// tile i leave during the K loop of tile i+1.  r4 measurements behind it (tools/gemm_bench.hip, profiles/r4_gemm.md): at
+// M = 12288, N = 4096, K = 1024 the 100 MB of bf16 activations cost 18 us of a 98 us launch because every CU reaches its
+// epilogue at the same time (a 5.5 TB/s burst, HBM-write bound, three times per launch), and each tile pays its own 2-stage
+// DMA prologue.  Here
+//  * after a tile's last K stage the accumulators are finished in registers (bias, activation or per-head RMSNorm, bf16
+//    rounding), transposed once through a private 4 KB LDS tile per wave and kept as twelve 16-byte store-ready pieces
+//    (48 VGPRs: the 256x192 tile leaves room for them at 2 waves per SIMD, the 256x256 tile does not);
+//  * the next tile's first two K stages are requested BEFORE that conversion (both ring slots are free behind the last
+//    stage's barrier), so the DMA prologue runs under it;
+//  * the twelve stores are issued four per stage behind the barriers of K stages 1-3 of the next tile, where they queue
+//    behind the stage's DMA requests instead of in front of a whole-chip burst.  Only a workgroup's last tile stores at once.
+// V^T tiles (head split, transposed target) stage as [feature][key position] and leave as 16-byte runs of 8 keys.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pring_kernel(GemmP p) {
+  constexpr int NW = 8, WGT = 2, NI = 2, NJ = 3, BF = 256, BT = 192, WB = BF * 128, STAGEB = (BF + BT) * 128;
+  constexpr int NPWW = BF / 8 / NW, NPWX = BT / 8 / NW, NPW = NPWW + NPWX, NM = NI * NJ, NR = NI + NJ;
+  constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
+  static_assert(kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_HEADS, "bf16-output epilogues only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wid / WGT, wt = wid % WGT;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nft = p.N / BF, ntt = p.M / BT, ntiles = nft * ntt;          // full tiles only (checked by the launcher)
+  const int ns = p.K / 64;                                              // >= 5 (launcher)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  char* const stg = smem + 2 * STAGEB + wid * 4096;                     // this wave's transposition tile
+
+  // tile index -> (feature tile, token tile): the XCD-aware map of the one-tile kernels applied to the persistent index
+  // (gridDim.x is a multiple of 8, so all tiles of a workgroup belong to its own XCD's share)
+  auto tile_coords = [&](int b, int& ft, int& tt) __attribute__((always_inline)) {
+    const int xcd = b & 7, slot = b >> 3;
+    if ((ntt & 7) == 0 && (nft & 3) == 0) {
+      const int rows = ntt >> 3;
+      const int g = slot / (rows * 4), rem = slot - g * rows * 4;
+      ft = g * 4 + (rem & 3);
+      tt = xcd * rows + (rem >> 2);
+    } else {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+      ft = tile % nft; tt = tile / nft;
+    }
+  };
+
+  // DMA sources (full tiles: the lane offsets do not depend on the tile)
+  const int r8 = lane >> 3, c8 = lane & 7;
+  uint32_t soff[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int rt = 8 * (q < NPWW ? wid * NPWW + q : wid * NPWX + (q - NPWW)) + r8;
+    const int chunk = c8 ^ ((rt >> 1) & 7);
+    soff[q] = (uint32_t)(((int64_t)rt * (q < NPWW ? p.ldw : p.ldx) + chunk * 8) * 2);
+  }
+  const int dW0 = wid * NPWW * 1024, dX0 = WB + wid * NPWX * 1024;
+#define P_ISSUE1(WBASE, XBASE, s, q)                                                                          \
+  lds_dma16_s(((q) < NPWW ? (WBASE) : (XBASE)) + (int64_t)(s) * 128, soff[q],                                 \
+              lds0 + ((s) & 1) * STAGEB + ((q) < NPWW ? dW0 + (q) * 1024 : dX0 + ((q) - NPWW) * 1024))
+
+  const int key = (l31 >> 1) & 7;
+  const int a_row = (wf * 32 * NI + l31) * 128;
+  const int b_row = WB + (wt * 32 * NJ + l31) * 128;
+#define P_RDA(s, ks, i) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + a_row + (i) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+#define P_RDB(s, ks, j) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + b_row + (j) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t pk[12];                       // the previous tile, store-ready: piece 4 * j + it of token block j
+  char* sbase[NJ];                      // its store addresses: sbase[j] + it * sstride
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pk[i] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sbase[j] = nullptr;
+  int64_t sstride = 0;
+  bool have_prev = false;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int ft, tt;
+  tile_coords(tile, ft, tt);
+  const char* Wb = reinterpret_cast<const char*>(p.W + (int64_t)ft * BF * p.ldw);
+  const char* Xb = reinterpret_cast<const char*>(p.X + (int64_t)tt * BT * p.ldx);
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) P_ISSUE1(Wb, Xb, 0, q);
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) P_ISSUE1(Wb, Xb, 1, q);
+
+  f32x16 acc[NI][NJ];
+  bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
+#define P_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
+  constexpr int D1 = 4, LH = D1 + (NPW - D1 + 1) / 2;       // DMA pieces right behind the barrier / in the next stage's first two substeps
+#define P_PHASE(CA, CB, NA, NB, s2, ks2, LATE, L0, L1)                                                    \
+  _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                        \
+    P_MMA(CA, CB, n);                                                                                     \
+    if (n < NI) NA[n] = P_RDA(s2, ks2, n);                                                                \
+    else if (n < NR) NB[n - NI] = P_RDB(s2, ks2, n - NI);                                                 \
+    if (LATE) {                                                                                           \
+      _Pragma("unroll") for (int d = (L0); d < (L1); ++d)                                                 \
+          if ((d - (L0)) * NM / ((L1) - (L0)) == n) P_ISSUE1(Wb, Xb, (s2) + 1, d);                        \
+    }                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  }
+#define P_SYNC()                                                                                          \
+  {                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                         \
+  }
+  // HK >= 0: behind this stage's barrier the stores 4 * HK .. 4 * HK + 3 of the previous tile are issued (slots 2-5)
+#define P_STAGE(s, PREV, FILL, HK)                                                                        \
+  {                                                                                                       \
+    P_PHASE(a0, b0, a1, b1, s, 1, PREV, D1, LH);                                                          \
+    P_PHASE(a1, b1, a0, b0, s, 2, PREV, LH, NPW);                                                         \
+    P_PHASE(a0, b0, a1, b1, s, 3, false, 0, 1);                                                           \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
+      P_MMA(a1, b1, n);                                                                                   \
+      if (n == 0) P_SYNC();                                                                               \
+      if (n >= 1 && n - 1 < NI) a0[n - 1] = P_RDA((s) + 1, 0, n - 1);                                     \
+      else if (n >= 1 && n - 1 < NR) b0[n - 1 - NI] = P_RDB((s) + 1, 0, n - 1 - NI);                      \
+      if (FILL) {                                                                                         \
+        _Pragma("unroll") for (int d = 0; d < D1; ++d)                                                    \
+            if (1 + d * (NM - 1) / D1 == n) P_ISSUE1(Wb, Xb, (s) + 2, d);                                 \
+      }                                                                                                   \
+      if ((HK) >= 0 && n >= 2) {                                                                          \
+        if (have_prev) __builtin_nontemporal_store(pk[4 * ((HK) < 0 ? 0 : (HK)) + n - 2],                 \
+                                                   reinterpret_cast<u32x4_t*>(sbase[(HK) < 0 ? 0 : (HK)] + (int64_t)(n - 2) * sstride)); \
+      }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+  }
+
+  for (;;) {
+    const int t0 = tt * BT;
+    // ---- stage 0 of this tile has landed (stage 1 may still be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a0[i] = P_RDA(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b0[j] = P_RDB(0, 0, j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // only LDS reads pending at the loop head: counted lgkmcnt waits inside (see the ring kernel)
+
+    // ---- K loop: stages 0 .. ns-2 (stage s+2 requested behind the barrier of stage s), stores of the previous tile in stages 1-3
+    P_STAGE(0, false, true, -1);
+    P_STAGE(1, true, true, 0);
+    P_STAGE(2, true, true, 1);
+    P_STAGE(3, true, ns > 5, 2);
+    int s = 4;
+    for (; s + 2 < ns; ++s) P_STAGE(s, true, true, -1);
+    if (s + 1 < ns) { P_STAGE(s, true, false, -1); ++s; }
+
+    // ---- last stage; behind its barrier both slots are free: request the next tile's first two stages
+    const int ntile = tile + gridDim.x;
+    const bool more = ntile < ntiles;
+    int nft_ = ft, ntt_ = tt;
+    if (more) tile_coords(ntile, nft_, ntt_);
+    const char* nWb = reinterpret_cast<const char*>(p.W + (int64_t)nft_ * BF * p.ldw);
+    const char* nXb = reinterpret_cast<const char*>(p.X + (int64_t)ntt_ * BT * p.ldx);
+    // bias / norm-weight quads of this tile are fetched NOW and waited for before the next tile's DMAs are issued: vmcnt counts
+    // in order, so a compiler-placed wait for them behind those DMAs would also wait for the DMAs (hipcc does not see the asm
+    // LDS-DMAs) and the conversion below would start only after the next tile's prologue has landed.  pk[] is dead here.
+    const int fw0 = ft * BF + wf * 64;
+    int which = 0, hh = 0;
+    bool vt = false;
+    const float* nw = nullptr;
+    if constexpr (EPI == LN3D_EPI_HEADS) {
+      const int dm = p.heads * 64;
+      which = fw0 / dm; hh = (fw0 - which * dm) >> 6;
+      vt = (p.transpose_mask >> which) & 1;
+      nw = which == 0 ? p.hn0 : (which == 1 ? p.hn1 : nullptr);
+    }
+    float4 bq[2][4], wq[2][4];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { bq[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f); wq[ii][g] = make_float4(1.f, 1.f, 1.f, 1.f); }
+    if (p.bias) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[ii][g] = *reinterpret_cast<const float4*>(p.bias + fw0 + ii * 32 + 8 * g + 4 * hi);
+    }
+    if constexpr (EPI == LN3D_EPI_HEADS) {
+      if (nw) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) wq[ii][g] = *reinterpret_cast<const float4*>(nw + ii * 32 + 8 * g + 4 * hi);
+      }
+    }
+    {
+      P_PHASE(a0, b0, a1, b1, s, 1, false, 0, 1);
+      P_PHASE(a1, b1, a0, b0, s, 2, false, 0, 1);
+      P_PHASE(a0, b0, a1, b1, s, 3, false, 0, 1);
+#pragma unroll
+      for (int n = 0; n < NM; ++n) {
+        P_MMA(a1, b1, n);
+        if (n == 0) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }     // vmcnt(0) (bias quads) + lgkmcnt(0)
+        if (more && n >= 1) {
+          if (n == 1) { P_ISSUE1(nWb, nXb, 0, 0); P_ISSUE1(nWb, nXb, 0, 1); P_ISSUE1(nWb, nXb, 0, 2); }
+          if (n == 2) { P_ISSUE1(nWb, nXb, 0, 3); P_ISSUE1(nWb, nXb, 0, 4); P_ISSUE1(nWb, nXb, 0, 5); }
+          if (n == 3) { P_ISSUE1(nWb, nXb, 0, 6); P_ISSUE1(nWb, nXb, 1, 0); P_ISSUE1(nWb, nXb, 1, 1); }
+          if (n == 4) { P_ISSUE1(nWb, nXb, 1, 2); P_ISSUE1(nWb, nXb, 1, 3); P_ISSUE1(nWb, nXb, 1, 4); }
+          if (n == 5) { P_ISSUE1(nWb, nXb, 1, 5); P_ISSUE1(nWb, nXb, 1, 6); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- finish the tile in registers -> pk[] (the stores of the tile before it were all issued in stages 1-3)
+    {
+      const int tw0 = t0 + wt * 96;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int tb = tw0 + 32 * j;
+        float rs = 1.0f;
+        if constexpr (EPI == LN3D_EPI_HEADS) {
+          if (nw) {      // wave-uniform: per-head RMSNorm of q / k over the 64 features of (token l31): 32 here, 32 in lane ^ 32
+            float ss = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float v0 = acc[ii][j][4 * g + 0] + bq[ii][g].x, v1 = acc[ii][j][4 * g + 1] + bq[ii][g].y,
+                            v2 = acc[ii][j][4 * g + 2] + bq[ii][g].z, v3 = acc[ii][j][4 * g + 3] + bq[ii][g].w;
+                ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+              }
+            ss += __shfl_xor(ss, 32, 64);
+            rs = rsqrtf(ss * (1.0f / 64.0f) + p.hn_eps);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v0 = acc[ii][j][4 * g + 0] + bq[ii][g].x, v1 = acc[ii][j][4 * g + 1] + bq[ii][g].y,
+                  v2 = acc[ii][j][4 * g + 2] + bq[ii][g].z, v3 = acc[ii][j][4 * g + 3] + bq[ii][g].w;
+            if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+            if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+            if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+            if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
+            if constexpr (EPI == LN3D_EPI_HEADS) {
+              if (nw) { v0 *= rs * wq[ii][g].x; v1 *= rs * wq[ii][g].y; v2 *= rs * wq[ii][g].z; v3 *= rs * wq[ii][g].w; }
+            }
+            const uint32_t lo = pack2bf(v0, v1), hi2 = pack2bf(v2, v3);
+            if (!vt) {
+              // [32 tokens][64 features] bf16, 8-byte piece c of row r at piece c ^ ((r & 7) << 1): 16-byte read-back pieces stay in order
+              const int c = ii * 8 + 2 * g + hi;
+              *reinterpret_cast<uint2*>(stg + l31 * 128 + ((c ^ ((l31 & 7) << 1)) << 3)) = make_uint2(lo, hi2);
+            } else {
+              // [64 features][32 key positions] bf16; position = token with bits 2 and 3 swapped (attention kernel's key order)
+              const int tp = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+              bf16_t* e = reinterpret_cast<bf16_t*>(stg + (ii * 32 + 8 * g + 4 * hi) * 64 + tp * 2);
+              e[0] = (bf16_t)(lo & 0xffffu); e[32] = (bf16_t)(lo >> 16); e[64] = (bf16_t)(hi2 & 0xffffu); e[96] = (bf16_t)(hi2 >> 16);
+            }
+          }
+        // read back 16 bytes per lane (DS operations of one wave execute in order: no barrier)
+        if (!vt) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = 8 * it + r8;
+            pk[4 * j + it] = *reinterpret_cast<const u32x4_t*>(stg + row * 128 + (((2 * c8) ^ ((row & 7) << 1)) << 3));
+          }
+        } else {
+          const int fr = lane >> 2, c = lane & 3;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) pk[4 * j + it] = *reinterpret_cast<const u32x4_t*>(stg + (16 * it + fr) * 64 + c * 16);
+        }
+        // store addresses of the block
+        if constexpr (EPI == LN3D_EPI_HEADS) {
+          const int b = tb / p.tokens, t = tb - b * p.tokens;
+          bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+          if (!vt) {
+            sbase[j] = reinterpret_cast<char*>(dst + (((int64_t)b * p.heads + hh) * p.tok_pad + t + r8) * 64 + 8 * c8);
+            sstride = 8 * 64 * 2;
+          } else {
+            sbase[j] = reinterpret_cast<char*>(dst + (((int64_t)b * p.heads + hh) * 64 + (lane >> 2)) * p.tok_pad + t + 8 * (lane & 3));
+            sstride = (int64_t)16 * p.tok_pad * 2;
+          }
+        } else {
+          sbase[j] = reinterpret_cast<char*>((bf16_t*)p.out0 + (int64_t)(tb + r8) * p.ldo + fw0 + 8 * c8);
+          sstride = (int64_t)8 * p.ldo * 2;
+        }
+      }
+      have_prev = true;
+    }
+    if (!more) break;
+    tile = ntile; ft = nft_; tt = ntt_; Wb = nWb; Xb = nXb;
+  }
+  // ---- the workgroup's last tile
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_nontemporal_store(pk[4 * j + it], reinterpret_cast<u32x4_t*>(sbase[j] + (int64_t)it * sstride));
+}
+
+template <int EPI>
+static int launch_pring(const GemmP& p, hipStream_t s) {
+  constexpr int LDSB = 2 * (256 + 192) * 128 + 8 * 4096;
+  static AttrOnce attr_once;
+  if (attr_once.need())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pring_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+  const int ntiles = (p.N / 256) * (p.M / 192);
+  int grid = num_cus() & ~7;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), LDSB, s, p);
+  return ln3d_check_launch();
+}
+
 template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
@@ -976,16 +1363,6 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
   }
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
 
 // Tile selection.  Small problems (per-sample adaLN / timestep GEMMs, the conv decoder's 32/64 channels) take the 128x128
 // kernel.  Otherwise the ring configuration with the least estimated time: rounds of one tile per CU x tile area / relative
@@ -1007,7 +1384,7 @@ static int forced_cfg() {
 }
 extern "C" void ln3d_gemm_reload_env(void) { g_gemm_abl = -1; g_gemm_forced = -2; }
 static int pick_cfg(int M, int N, bool head_aligned = false) {
-  if (forced_cfg() >= 0) return forced_cfg();
+  if (forced_cfg() >= 0 && forced_cfg() != 15) return forced_cfg();      // x15 = the persistent kernel where legal, the automatic choice elsewhere
   if (!(M >= 1536 && N >= 128)) return 0;
   static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
                                                                {8, 128, 384, 0.945f}};
@@ -1029,6 +1406,30 @@ static int pick_cfg(int M, int N, bool head_aligned = false) {
     if (t14 > best_tiles) best = 14;
   }
   return best;
+}
+
+// The persistent deferred-store kernel (gemm_bf16_pring_kernel) takes bf16-output problems made of full 256x192 tiles with at
+// least two tiles per CU; everything else stays on the one-tile-per-workgroup kernels.  LN3D_GEMM_TILE=x15 forces it where it is
+// legal, any other forced tile disables it (A/B runs).
+static bool pring_eligible(const ln3d_gemm_args* a) {
+  const int e = a->epilogue;
+  if (!(e == LN3D_EPI_BF16 || e == LN3D_EPI_GELU_ERF || e == LN3D_EPI_GELU_TANH || e == LN3D_EPI_SILU || e == LN3D_EPI_QUICK_GELU ||
+        e == LN3D_EPI_HEADS))
+    return false;
+  if (forced_cfg() >= 0 && forced_cfg() != 15) return false;
+  if ((a->N % 256) != 0 || (a->M % 192) != 0 || a->K < 320) return false;
+  const int64_t tiles = (int64_t)(a->N / 256) * (a->M / 192);
+  if (forced_cfg() != 15 && tiles < 2 * (int64_t)num_cus()) return false;
+  if (((uintptr_t)a->out0 & 15) != 0 || (a->bias && ((uintptr_t)a->bias & 15) != 0)) return false;
+  if (e == LN3D_EPI_HEADS) {
+    const int pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
+    if (a->head_dim != 64 || pad != 64 || a->heads <= 0 || ((a->heads * 64) % 256) != 0 || (a->N % (a->heads * 64)) != 0 || a->N > 3 * a->heads * 64)
+      return false;
+    if (a->tokens <= 0 || (a->tokens % 32) != 0 || (a->M % a->tokens) != 0 || (a->tok_pad % 8) != 0) return false;
+    if (!a->out1 || (a->N > 2 * a->heads * 64 && !a->out2)) return false;
+    if (((uintptr_t)a->out1 & 15) != 0 || ((uintptr_t)a->out2 & 15) != 0) return false;
+  } else if ((a->ldo % 8) != 0) return false;
+  return true;
 }
 
 extern "C" int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int head_dim_pad) {
@@ -1056,6 +1457,19 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
   p.rb = a->epilogue == LN3D_EPI_GATE_RES ? a->res_bias : nullptr; p.rb_ld = a->res_bias_ld;
   hipStream_t s = (hipStream_t)stream;
+  if (pring_eligible(a)) {
+    switch (a->epilogue) {
+      case LN3D_EPI_BF16: return launch_pring<LN3D_EPI_BF16>(p, s);
+      case LN3D_EPI_GELU_ERF: return launch_pring<LN3D_EPI_GELU_ERF>(p, s);
+      case LN3D_EPI_GELU_TANH: return launch_pring<LN3D_EPI_GELU_TANH>(p, s);
+      case LN3D_EPI_SILU: return launch_pring<LN3D_EPI_SILU>(p, s);
+      case LN3D_EPI_QUICK_GELU: return launch_pring<LN3D_EPI_QUICK_GELU>(p, s);
+      case LN3D_EPI_HEADS:
+        if (a->tok_pad < a->tokens) return LN3D_ERR_BAD_ARG;
+        return launch_pring<LN3D_EPI_HEADS>(p, s);
+      default: break;
+    }
+  }
   const int cfg = pick_cfg(a->M, a->N, a->epilogue == LN3D_EPI_HEADS && a->head_dim == 64 && a->head_dim_pad <= 64);
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);
