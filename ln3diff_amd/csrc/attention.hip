@@ -26,8 +26,6 @@ struct AttnP {
 
 #define KVB 64
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // One workgroup = 8 waves = 256 query rows of one (batch, head): K / V^T stream from L2 ONCE per 256 queries
 // (the stream, not the MFMA, bounds this kernel: K+V of one head is 196 KB against 50 MFLOP per 256 queries).
@@ -95,8 +93,8 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     const int kb_i_ = (kbv);                                                                                  \
     char* sb_ = smem + (kb_i_ % NST) * STAGEB;                                                                \
     _Pragma("unroll") for (int ii_ = 0; ii_ < LPW; ++ii_) {                                                   \
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(ksrc[ii_] + (int64_t)kb_i_ * KVB * DH), (lds_void_t*)(sb_ + kdst[ii_]), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(vsrc[ii_] + kb_i_ * KVB), (lds_void_t*)(sb_ + vdst[ii_]), 16, 0, 0); \
+      lds_dma16_v((ksrc[ii_] + (int64_t)kb_i_ * KVB * DH), lds_addr((sb_ + kdst[ii_]))); \
+      lds_dma16_v((vsrc[ii_] + kb_i_ * KVB), lds_addr((sb_ + vdst[ii_]))); \
     }                                                                                                         \
   }
 
@@ -330,8 +328,8 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
   auto issue_stage = [&](auto slot_tag) __attribute__((always_inline)) {   // slot relative to the current half: 0..7
     constexpr int SL = decltype(slot_tag)::value & (NST - 1);
     char* dst = smem + ((SL >= 4 ? half_base ^ 65536 : half_base) + (SL & 3) * STAGEB + wid * 1024);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs), (lds_void_t*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs), (lds_void_t*)(dst + KTILE), 16, 0, 0);
+    lds_dma16_s(kq, koffs, lds_addr(dst));
+    lds_dma16_s(vq, voffs, lds_addr(dst + KTILE));
     ++kb_issue; kq += 64 * DH * 2; vq += 64 * 2;          // the stream wraps around the head's keys at every query block
     if (kb_issue == nkb) { kb_issue = 0; kq = Kg; vq = Vg; }
   };
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnP p) {
     for (int j = 0; j < 4; ++j) {
       const int row = j * 8 + (lane >> 3);
       int qr = qb * QB + wid * 32 + row; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), (lds_void_t*)(wstage + j * 1024), 16, 0, 0);
+      lds_dma16_v((Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), lds_addr((wstage + j * 1024)));
     }
   };
   // (the caller has waited for the DMA)  fragments, scaled by scale * log2(e) and rounded to bf16 once more
@@ -659,12 +657,12 @@ __global__ __launch_bounds__(512, 2) void attn_kres_kernel(AttnP p) {
   const char* kq = Kg; const char* vq = Vg;               // scalar: source of the next K block / V^T stage to issue
   int kb_k = 0, kb_v = 0;
   auto issue_k = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(kq + koffs), (lds_void_t*)(smem + kb_k * 8192 + wid * 1024), 16, 0, 0);
+    lds_dma16_s(kq, koffs, lds0 + kb_k * 8192 + wid * 1024);
     ++kb_k; kq += 64 * DH * 2;
   };
   auto issue_v = [&](auto slot_tag) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot_tag)::value & 3;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(vq + voffs), (lds_void_t*)(smem + VRING + SL * VSLOT + wid * 1024), 16, 0, 0);
+    lds_dma16_s(vq, voffs, lds0 + VRING + SL * VSLOT + wid * 1024);
     ++kb_v; vq += 64 * 2;                                 // the stream wraps around the head's keys at every query block
     if (kb_v == nkb) { kb_v = 0; vq = Vg; }
   };
@@ -675,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void attn_kres_kernel(AttnP p) {
     for (int j = 0; j < 4; ++j) {
       const int row = j * 8 + (lane >> 3);
       int qr = qb * QB + wid * 32 + row; qr = qr < p.Nq_pad ? qr : p.Nq_pad - 1;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), (lds_void_t*)(wstage + j * 1024), 16, 0, 0);
+      lds_dma16_v((Qg + (int64_t)qr * DH + (((lane & 7) ^ ((row >> 1) & 7)) * 8)), lds_addr((wstage + j * 1024)));
     }
   };
   auto scale_q = [&](uint32_t (&u)[4]) __attribute__((always_inline)) {
@@ -1002,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void attn_kres_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     for (int kb = 0; kb < nkb; ++kb) {
       __builtin_amdgcn_s_barrier();                       // ring slot 0 is free (previous block of keys consumed by every wave)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Vg + kb * 128 + voffs), (lds_void_t*)(smem + VRING + wid * 1024), 16, 0, 0);
+      lds_dma16_v((Vg + kb * 128 + voffs), lds_addr((smem + VRING + wid * 1024)));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       f32x16 st[2];
@@ -1084,8 +1082,8 @@ __global__ __launch_bounds__(256, 3) void attn_short_kernel(AttnP p) {
         const bf16_t* ks = Kg + (int64_t)(kb * KVB + krow) * DH + ((kcp ^ ((krow >> 1) & 7)) * 8);
         const int vrow = j * 8 + (lane >> 3), vcp = lane & 7;
         const bf16_t* vs = Vg + (int64_t)vrow * p.Nk_pad + kb * KVB + ((vcp ^ ((vrow >> 1) & 7)) * 8);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)ks, (lds_void_t*)(smem + kb * STAGEB + j * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)vs, (lds_void_t*)(smem + kb * STAGEB + KTILE + j * 1024), 16, 0, 0);
+        lds_dma16_v(ks, lds_addr((smem + kb * STAGEB + j * 1024)));
+        lds_dma16_v(vs, lds_addr((smem + kb * STAGEB + KTILE + j * 1024)));
       }
     }
   }

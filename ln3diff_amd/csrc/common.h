@@ -91,6 +91,25 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 // torch.nn.functional.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// LDS-DMA issued as inline asm, not through __builtin_amdgcn_global_load_lds.  r4 finding: hipcc's wait-count pass files the
+// builtin as a FLAT access that touches both VMEM and LDS ("pending flat"), and from the first one on it answers every later
+// LDS dependency with s_waitcnt lgkmcnt(0) instead of a counted wait - the K loop then drains the fragment read it issued one
+// MFMA ago at the head of every K substep, with both waves of a SIMD in the same phase (profiles/r4_gemm.md; the attention kernels had 137 lgkmcnt(0) waits and not one counted wait).  The asm
+// form is invisible to that pass: fragment reads get counted lgkmcnt(N) waits, and the DMA's own completion is waited for by
+// hand (counted s_waitcnt vmcnt) as before.  M0 = LDS byte address of the wave's 1 KB piece; one wait state between the M0
+// write and the DMA (LDS-DMA reads M0).
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds) {      // wave-uniform base + 32-bit lane offset
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_v(const void* vaddr, uint32_t lds) {                     // per-lane 64-bit address
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
+// LDS byte address of a pointer into the dynamic shared segment
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_void_t*)p; }
+
 // hipFuncSetAttribute applies to the CURRENT device: remembered per (kernel instantiation, device) so that a process driving several
 // GPUs sets it on each of them (one process per GPU is the deployment, but the library must not depend on it)
 struct AttrOnce {

@@ -39,12 +39,6 @@ struct GemmP {
   int ctx_keys, ctx_pad; float ctx_scale_log2;
   const float* hn0; const float* hn1; float hn_eps;   // HEADS: fused qk_norm weights (outputs 0 / 1) or NULL
   const float* rb; int64_t rb_ld;                      // GATE_RES: per-sample row added after gating (sample = row / gate_rows) or NULL
-  // Measurement bits of the ring kernel (LN3D_GEMM_ABL, read once per process; 0 in every product run): 1 = skip the epilogue,
-  // 2 = 2 K-stages only, 4 = no DMA in steady state.  They stay RUNTIME branches on purpose: r3 compiled them out and hipcc's register
-  // allocation of the 12-wave QKV tile (168-VGPR cap) went from 13 spilled registers outside the K loop to 73 with scratch traffic
-  // inside it (bench 2.49 -> 2.23 samples/s); neither unroll pragmas, an opaque loop start nor 32-bit DMA offsets brought the old
-  // allocation back, the two never-taken branches do.
-  int abl;
 };
 
 template <int EPI>
@@ -463,7 +457,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             u32x4_t ov = {o.x, o.y, o.z, o.w};
             u32x4_t* dstp = reinterpret_cast<u32x4_t*>((bf16_t*)p.out0 + (int64_t)(tb + row) * p.ldo + f8);
-            __builtin_nontemporal_store(ov, dstp);   // streaming store: the activations are read once, by the next kernel (fc1 -3 us, within box noise)
+            // plain store, NOT nontemporal: the next kernel reads these activations, and in the pipeline a streaming store
+            // sends them past the 256 MB memory-side cache (same-box A/B of the whole bench line, r4: 2.62 -> 2.65 samples/s)
+            *dstp = ov;
           }
         }
       } else if constexpr (EPI == LN3D_EPI_GATE_RES) {
@@ -569,24 +565,9 @@ static int num_cus() {
   return n;
 }
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
 
-// LDS-DMA issued as inline asm, not through __builtin_amdgcn_global_load_lds.  r4 finding: hipcc's wait-count pass files the
-// builtin as a FLAT access that touches both VMEM and LDS ("pending flat"), and from the first one on it answers every later
-// LDS dependency with s_waitcnt lgkmcnt(0) instead of a counted wait - the K loop then drains the fragment read it issued one
-// MFMA ago at the head of every K substep, with both waves of a SIMD in the same phase (profiles/r4_gemm_timeline.md).  The asm
-// form is invisible to that pass: fragment reads get counted lgkmcnt(N) waits, and the DMA's own completion is waited for by
-// hand (counted s_waitcnt vmcnt) as before.  M0 = LDS byte address of the wave's 1 KB piece; one wait state between the M0
-// write and the DMA (LDS-DMA reads M0).
-__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds) {      // wave-uniform base + 32-bit lane offset
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
-}
-__device__ __forceinline__ void lds_dma16_v(const void* vaddr, uint32_t lds) {                     // per-lane 64-bit address
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
-}
 #ifndef LN3D_RING_D1
-#define LN3D_RING_D1 0       // DMA pieces of a stage issued right behind the barrier (0 = all of them); the rest in the next two substeps
+#define LN3D_RING_D1 0       // DMA pieces of a stage issued right behind the barrier (0 = half of them); the rest in the next two substeps
 #endif
 #ifndef LN3D_RING_ABL
 #define LN3D_RING_ABL 0     // bench builds only: 1 = skip the epilogue, 2 = two K stages only, 4 = no DMA in the steady state, 8 = per-stage s_memtime stamps into out2
@@ -715,7 +696,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   // D1 of a stage's NPW DMA instructions are issued in the last substep of stage s (right behind the barrier that retires
   // their slot), the other NPW - D1 in the first two substeps of stage s+1 (LATE slots apart): the texture path accepts a
   // 1 KB piece every ~16 cycles and a wave that finds its queue full stalls with its MFMAs behind it.
-  constexpr int D1 = (LN3D_RING_D1 > 0 && LN3D_RING_D1 < NPW) ? LN3D_RING_D1 : NPW;
+  constexpr int D1 = LN3D_RING_D1 > 0 ? (LN3D_RING_D1 < NPW ? LN3D_RING_D1 : NPW) : (NPW + 1) / 2;
   constexpr int NLATE = NPW - D1;
   // substep: multiply (CA, CB) while (s2, ks2) is read into (NA, NB); LATE0 >= 0: late DMA pieces [LATE0, LATE1) of stage sd
 #define Y_PHASE(CA, CB, NA, NB, s2, ks2, LATE, sd, L0, L1)                                                \
@@ -1001,323 +982,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   staged_epilogue<EPI, NI, NJ, (NW <= 8)>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Persistent ring kernel for the bf16-output GEMMs with several tiles per CU (fc1 + GELU, QKV + head split, plain bf16): one
-// 8-wave workgroup per CU walks its tiles (256 features x 192 tokens, wave tile 64 x 96 like configuration 9) and the STORES of
-// tile i leave during the K loop of tile i+1.  r4 measurements behind it (tools/gemm_bench.hip, profiles/r4_gemm.md): at
-// M = 12288, N = 4096, K = 1024 the 100 MB of bf16 activations cost 18 us of a 98 us launch because every CU reaches its
-// epilogue at the same time (a 5.5 TB/s burst, HBM-write bound, three times per launch), and each tile pays its own 2-stage
-// DMA prologue.  Here
-//  * after a tile's last K stage the accumulators are finished in registers (bias, activation or per-head RMSNorm, bf16
-//    rounding), transposed once through a private 4 KB LDS tile per wave and kept as twelve 16-byte store-ready pieces
-//    (48 VGPRs: the 256x192 tile leaves room for them at 2 waves per SIMD, the 256x256 tile does not);
-//  * the next tile's first two K stages are requested BEFORE that conversion (both ring slots are free behind the last
-//    stage's barrier), so the DMA prologue runs under it;
-//  * the twelve stores are issued four per stage behind the barriers of K stages 1-3 of the next tile, where they queue
-//    behind the stage's DMA requests instead of in front of a whole-chip burst.  Only a workgroup's last tile stores at once.
-// V^T tiles (head split, transposed target) stage as [feature][key position] and leave as 16-byte runs of 8 keys.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pring_kernel(GemmP p) {
-  constexpr int NW = 8, WGT = 2, NI = 2, NJ = 3, BF = 256, BT = 192, WB = BF * 128, STAGEB = (BF + BT) * 128;
-  constexpr int NPWW = BF / 8 / NW, NPWX = BT / 8 / NW, NPW = NPWW + NPWX, NM = NI * NJ, NR = NI + NJ;
-  constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
-  static_assert(kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_HEADS, "bf16-output epilogues only");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wf = wid / WGT, wt = wid % WGT;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int nft = p.N / BF, ntt = p.M / BT, ntiles = nft * ntt;          // full tiles only (checked by the launcher)
-  const int ns = p.K / 64;                                              // >= 5 (launcher)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-  char* const stg = smem + 2 * STAGEB + wid * 4096;                     // this wave's transposition tile
-
-  // tile index -> (feature tile, token tile): the XCD-aware map of the one-tile kernels applied to the persistent index
-  // (gridDim.x is a multiple of 8, so all tiles of a workgroup belong to its own XCD's share)
-  auto tile_coords = [&](int b, int& ft, int& tt) __attribute__((always_inline)) {
-    const int xcd = b & 7, slot = b >> 3;
-    if ((ntt & 7) == 0 && (nft & 3) == 0) {
-      const int rows = ntt >> 3;
-      const int g = slot / (rows * 4), rem = slot - g * rows * 4;
-      ft = g * 4 + (rem & 3);
-      tt = xcd * rows + (rem >> 2);
-    } else {
-      const int q = ntiles >> 3, r = ntiles & 7;
-      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-      ft = tile % nft; tt = tile / nft;
-    }
-  };
-
-  // DMA sources (full tiles: the lane offsets do not depend on the tile)
-  const int r8 = lane >> 3, c8 = lane & 7;
-  uint32_t soff[NPW];
-#pragma unroll
-  for (int q = 0; q < NPW; ++q) {
-    const int rt = 8 * (q < NPWW ? wid * NPWW + q : wid * NPWX + (q - NPWW)) + r8;
-    const int chunk = c8 ^ ((rt >> 1) & 7);
-    soff[q] = (uint32_t)(((int64_t)rt * (q < NPWW ? p.ldw : p.ldx) + chunk * 8) * 2);
-  }
-  const int dW0 = wid * NPWW * 1024, dX0 = WB + wid * NPWX * 1024;
-#define P_ISSUE1(WBASE, XBASE, s, q)                                                                          \
-  lds_dma16_s(((q) < NPWW ? (WBASE) : (XBASE)) + (int64_t)(s) * 128, soff[q],                                 \
-              lds0 + ((s) & 1) * STAGEB + ((q) < NPWW ? dW0 + (q) * 1024 : dX0 + ((q) - NPWW) * 1024))
-
-  const int key = (l31 >> 1) & 7;
-  const int a_row = (wf * 32 * NI + l31) * 128;
-  const int b_row = WB + (wt * 32 * NJ + l31) * 128;
-#define P_RDA(s, ks, i) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + a_row + (i) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
-#define P_RDB(s, ks, j) (*reinterpret_cast<const bf16x8*>(smem + ((s) & 1) * STAGEB + b_row + (j) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
-
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t pk[12];                       // the previous tile, store-ready: piece 4 * j + it of token block j
-  char* sbase[NJ];                      // its store addresses: sbase[j] + it * sstride
-#pragma unroll
-  for (int i = 0; i < 12; ++i) pk[i] = u32x4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) sbase[j] = nullptr;
-  int64_t sstride = 0;
-  bool have_prev = false;
-
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  int ft, tt;
-  tile_coords(tile, ft, tt);
-  const char* Wb = reinterpret_cast<const char*>(p.W + (int64_t)ft * BF * p.ldw);
-  const char* Xb = reinterpret_cast<const char*>(p.X + (int64_t)tt * BT * p.ldx);
-#pragma unroll
-  for (int q = 0; q < NPW; ++q) P_ISSUE1(Wb, Xb, 0, q);
-#pragma unroll
-  for (int q = 0; q < NPW; ++q) P_ISSUE1(Wb, Xb, 1, q);
-
-  f32x16 acc[NI][NJ];
-  bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
-#define P_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
-  constexpr int D1 = 4, LH = D1 + (NPW - D1 + 1) / 2;       // DMA pieces right behind the barrier / in the next stage's first two substeps
-#define P_PHASE(CA, CB, NA, NB, s2, ks2, LATE, L0, L1)                                                    \
-  _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                        \
-    P_MMA(CA, CB, n);                                                                                     \
-    if (n < NI) NA[n] = P_RDA(s2, ks2, n);                                                                \
-    else if (n < NR) NB[n - NI] = P_RDB(s2, ks2, n - NI);                                                 \
-    if (LATE) {                                                                                           \
-      _Pragma("unroll") for (int d = (L0); d < (L1); ++d)                                                 \
-          if ((d - (L0)) * NM / ((L1) - (L0)) == n) P_ISSUE1(Wb, Xb, (s2) + 1, d);                        \
-    }                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-  }
-#define P_SYNC()                                                                                          \
-  {                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                   \
-    __builtin_amdgcn_s_barrier();                                                                         \
-  }
-  // HK >= 0: behind this stage's barrier the stores 4 * HK .. 4 * HK + 3 of the previous tile are issued (slots 2-5)
-#define P_STAGE(s, PREV, FILL, HK)                                                                        \
-  {                                                                                                       \
-    P_PHASE(a0, b0, a1, b1, s, 1, PREV, D1, LH);                                                          \
-    P_PHASE(a1, b1, a0, b0, s, 2, PREV, LH, NPW);                                                         \
-    P_PHASE(a0, b0, a1, b1, s, 3, false, 0, 1);                                                           \
-    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                      \
-      P_MMA(a1, b1, n);                                                                                   \
-      if (n == 0) P_SYNC();                                                                               \
-      if (n >= 1 && n - 1 < NI) a0[n - 1] = P_RDA((s) + 1, 0, n - 1);                                     \
-      else if (n >= 1 && n - 1 < NR) b0[n - 1 - NI] = P_RDB((s) + 1, 0, n - 1 - NI);                      \
-      if (FILL) {                                                                                         \
-        _Pragma("unroll") for (int d = 0; d < D1; ++d)                                                    \
-            if (1 + d * (NM - 1) / D1 == n) P_ISSUE1(Wb, Xb, (s) + 2, d);                                 \
-      }                                                                                                   \
-      if ((HK) >= 0 && n >= 2) {                                                                          \
-        if (have_prev) __builtin_nontemporal_store(pk[4 * ((HK) < 0 ? 0 : (HK)) + n - 2],                 \
-                                                   reinterpret_cast<u32x4_t*>(sbase[(HK) < 0 ? 0 : (HK)] + (int64_t)(n - 2) * sstride)); \
-      }                                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                  \
-    }                                                                                                     \
-  }
-
-  for (;;) {
-    const int t0 = tt * BT;
-    // ---- stage 0 of this tile has landed (stage 1 may still be in flight)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < NI; ++i) a0[i] = P_RDA(0, 0, i);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) b0[j] = P_RDB(0, 0, j);
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // only LDS reads pending at the loop head: counted lgkmcnt waits inside (see the ring kernel)
-
-    // ---- K loop: stages 0 .. ns-2 (stage s+2 requested behind the barrier of stage s), stores of the previous tile in stages 1-3
-    P_STAGE(0, false, true, -1);
-    P_STAGE(1, true, true, 0);
-    P_STAGE(2, true, true, 1);
-    P_STAGE(3, true, ns > 5, 2);
-    int s = 4;
-    for (; s + 2 < ns; ++s) P_STAGE(s, true, true, -1);
-    if (s + 1 < ns) { P_STAGE(s, true, false, -1); ++s; }
-
-    // ---- last stage; behind its barrier both slots are free: request the next tile's first two stages
-    const int ntile = tile + gridDim.x;
-    const bool more = ntile < ntiles;
-    int nft_ = ft, ntt_ = tt;
-    if (more) tile_coords(ntile, nft_, ntt_);
-    const char* nWb = reinterpret_cast<const char*>(p.W + (int64_t)nft_ * BF * p.ldw);
-    const char* nXb = reinterpret_cast<const char*>(p.X + (int64_t)ntt_ * BT * p.ldx);
-    // bias / norm-weight quads of this tile are fetched NOW and waited for before the next tile's DMAs are issued: vmcnt counts
-    // in order, so a compiler-placed wait for them behind those DMAs would also wait for the DMAs (hipcc does not see the asm
-    // LDS-DMAs) and the conversion below would start only after the next tile's prologue has landed.  pk[] is dead here.
-    const int fw0 = ft * BF + wf * 64;
-    int which = 0, hh = 0;
-    bool vt = false;
-    const float* nw = nullptr;
-    if constexpr (EPI == LN3D_EPI_HEADS) {
-      const int dm = p.heads * 64;
-      which = fw0 / dm; hh = (fw0 - which * dm) >> 6;
-      vt = (p.transpose_mask >> which) & 1;
-      nw = which == 0 ? p.hn0 : (which == 1 ? p.hn1 : nullptr);
-    }
-    float4 bq[2][4], wq[2][4];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { bq[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f); wq[ii][g] = make_float4(1.f, 1.f, 1.f, 1.f); }
-    if (p.bias) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[ii][g] = *reinterpret_cast<const float4*>(p.bias + fw0 + ii * 32 + 8 * g + 4 * hi);
-    }
-    if constexpr (EPI == LN3D_EPI_HEADS) {
-      if (nw) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) wq[ii][g] = *reinterpret_cast<const float4*>(nw + ii * 32 + 8 * g + 4 * hi);
-      }
-    }
-    {
-      P_PHASE(a0, b0, a1, b1, s, 1, false, 0, 1);
-      P_PHASE(a1, b1, a0, b0, s, 2, false, 0, 1);
-      P_PHASE(a0, b0, a1, b1, s, 3, false, 0, 1);
-#pragma unroll
-      for (int n = 0; n < NM; ++n) {
-        P_MMA(a1, b1, n);
-        if (n == 0) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }     // vmcnt(0) (bias quads) + lgkmcnt(0)
-        if (more && n >= 1) {
-          if (n == 1) { P_ISSUE1(nWb, nXb, 0, 0); P_ISSUE1(nWb, nXb, 0, 1); P_ISSUE1(nWb, nXb, 0, 2); }
-          if (n == 2) { P_ISSUE1(nWb, nXb, 0, 3); P_ISSUE1(nWb, nXb, 0, 4); P_ISSUE1(nWb, nXb, 0, 5); }
-          if (n == 3) { P_ISSUE1(nWb, nXb, 0, 6); P_ISSUE1(nWb, nXb, 1, 0); P_ISSUE1(nWb, nXb, 1, 1); }
-          if (n == 4) { P_ISSUE1(nWb, nXb, 1, 2); P_ISSUE1(nWb, nXb, 1, 3); P_ISSUE1(nWb, nXb, 1, 4); }
-          if (n == 5) { P_ISSUE1(nWb, nXb, 1, 5); P_ISSUE1(nWb, nXb, 1, 6); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    // ---- finish the tile in registers -> pk[] (the stores of the tile before it were all issued in stages 1-3)
-    {
-      const int tw0 = t0 + wt * 96;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int tb = tw0 + 32 * j;
-        float rs = 1.0f;
-        if constexpr (EPI == LN3D_EPI_HEADS) {
-          if (nw) {      // wave-uniform: per-head RMSNorm of q / k over the 64 features of (token l31): 32 here, 32 in lane ^ 32
-            float ss = 0.f;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float v0 = acc[ii][j][4 * g + 0] + bq[ii][g].x, v1 = acc[ii][j][4 * g + 1] + bq[ii][g].y,
-                            v2 = acc[ii][j][4 * g + 2] + bq[ii][g].z, v3 = acc[ii][j][4 * g + 3] + bq[ii][g].w;
-                ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-              }
-            ss += __shfl_xor(ss, 32, 64);
-            rs = rsqrtf(ss * (1.0f / 64.0f) + p.hn_eps);
-          }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float v0 = acc[ii][j][4 * g + 0] + bq[ii][g].x, v1 = acc[ii][j][4 * g + 1] + bq[ii][g].y,
-                  v2 = acc[ii][j][4 * g + 2] + bq[ii][g].z, v3 = acc[ii][j][4 * g + 3] + bq[ii][g].w;
-            if constexpr (EPI == LN3D_EPI_GELU_ERF) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
-            if constexpr (EPI == LN3D_EPI_GELU_TANH) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-            if constexpr (EPI == LN3D_EPI_SILU) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
-            if constexpr (EPI == LN3D_EPI_QUICK_GELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
-            if constexpr (EPI == LN3D_EPI_HEADS) {
-              if (nw) { v0 *= rs * wq[ii][g].x; v1 *= rs * wq[ii][g].y; v2 *= rs * wq[ii][g].z; v3 *= rs * wq[ii][g].w; }
-            }
-            const uint32_t lo = pack2bf(v0, v1), hi2 = pack2bf(v2, v3);
-            if (!vt) {
-              // [32 tokens][64 features] bf16, 8-byte piece c of row r at piece c ^ ((r & 7) << 1): 16-byte read-back pieces stay in order
-              const int c = ii * 8 + 2 * g + hi;
-              *reinterpret_cast<uint2*>(stg + l31 * 128 + ((c ^ ((l31 & 7) << 1)) << 3)) = make_uint2(lo, hi2);
-            } else {
-              // [64 features][32 key positions] bf16; position = token with bits 2 and 3 swapped (attention kernel's key order)
-              const int tp = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-              bf16_t* e = reinterpret_cast<bf16_t*>(stg + (ii * 32 + 8 * g + 4 * hi) * 64 + tp * 2);
-              e[0] = (bf16_t)(lo & 0xffffu); e[32] = (bf16_t)(lo >> 16); e[64] = (bf16_t)(hi2 & 0xffffu); e[96] = (bf16_t)(hi2 >> 16);
-            }
-          }
-        // read back 16 bytes per lane (DS operations of one wave execute in order: no barrier)
-        if (!vt) {
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int row = 8 * it + r8;
-            pk[4 * j + it] = *reinterpret_cast<const u32x4_t*>(stg + row * 128 + (((2 * c8) ^ ((row & 7) << 1)) << 3));
-          }
-        } else {
-          const int fr = lane >> 2, c = lane & 3;
-#pragma unroll
-          for (int it = 0; it < 4; ++it) pk[4 * j + it] = *reinterpret_cast<const u32x4_t*>(stg + (16 * it + fr) * 64 + c * 16);
-        }
-        // store addresses of the block
-        if constexpr (EPI == LN3D_EPI_HEADS) {
-          const int b = tb / p.tokens, t = tb - b * p.tokens;
-          bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
-          if (!vt) {
-            sbase[j] = reinterpret_cast<char*>(dst + (((int64_t)b * p.heads + hh) * p.tok_pad + t + r8) * 64 + 8 * c8);
-            sstride = 8 * 64 * 2;
-          } else {
-            sbase[j] = reinterpret_cast<char*>(dst + (((int64_t)b * p.heads + hh) * 64 + (lane >> 2)) * p.tok_pad + t + 8 * (lane & 3));
-            sstride = (int64_t)16 * p.tok_pad * 2;
-          }
-        } else {
-          sbase[j] = reinterpret_cast<char*>((bf16_t*)p.out0 + (int64_t)(tb + r8) * p.ldo + fw0 + 8 * c8);
-          sstride = (int64_t)8 * p.ldo * 2;
-        }
-      }
-      have_prev = true;
-    }
-    if (!more) break;
-    tile = ntile; ft = nft_; tt = ntt_; Wb = nWb; Xb = nXb;
-  }
-  // ---- the workgroup's last tile
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-      __builtin_nontemporal_store(pk[4 * j + it], reinterpret_cast<u32x4_t*>(sbase[j] + (int64_t)it * sstride));
-}
-
-template <int EPI>
-static int launch_pring(const GemmP& p, hipStream_t s) {
-  constexpr int LDSB = 2 * (256 + 192) * 128 + 8 * 4096;
-  static AttrOnce attr_once;
-  if (attr_once.need())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pring_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-  const int ntiles = (p.N / 256) * (p.M / 192);
-  int grid = num_cus() & ~7;
-  if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), LDSB, s, p);
-  return ln3d_check_launch();
-}
-
 template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
@@ -1346,7 +1010,7 @@ static int launch(const GemmP& p, hipStream_t s) {
 }
 
 // cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (8 waves), 12 = 384f x 192t (12 waves,
-// 3 per SIMD), 11 = 384f x 192t with 8 waves (96x96 wave tiles; kept for A/B runs)
+// 3 per SIMD), 14 = 128f x 192t (4 waves).  r2's 384x192 / 8-wave and 256x256 / 4-wave variants (11, 13) were measured slower and are gone.
 template <int EPI>
 static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return cfg == 14 ? launch_ring64<EPI, 4, 2, 2, 3>(p, s) : launch_ring64<EPI, 8, 2, 2, 3>(p, s);
@@ -1355,10 +1019,8 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
     case 7: return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
     case 8: return launch_ring64<EPI, 8, 4, 2, 3>(p, s);
     case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
-    case 11: return launch_ring64<EPI, 8, 2, 3, 3>(p, s);
     case 12: return launch_ring64<EPI, 12, 2, 2, 3>(p, s);
-    case 13: return launch_ring64<EPI, 4, 2, 4, 4>(p, s);
-    case 14: return launch_ring64<EPI, 4, 2, 2, 3>(p, s);      // 128f x 192t, 4 waves, 80 KB: two workgroups per CU (epilogue of one under the main loop of the other)      // 256x256, 4 waves (1 per SIMD), 128x128 wave tiles, accumulators in AGPRs
+    case 14: return launch_ring64<EPI, 4, 2, 2, 3>(p, s);      // 128f x 192t, 4 waves, 80 KB: two workgroups per CU (the half-batch GEMMs)
     default: return launch<EPI>(p, s);
   }
 }
@@ -1370,11 +1032,7 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
 // fill is the limiter, so throughput follows the tile's flop/byte).  DiT-L/2 at 12288 tokens: N = 4096 -> 256x256 (3 full
 // rounds), N = 3072 -> 384x192 with 12 waves (2 full rounds), N = 1024 -> 256x192 (1 full round).
 // LN3D_GEMM_TILE (measurement switch, read once per process): s = the 128x128 register-staged kernel, x<cfg> = that ring configuration
-static int g_gemm_abl = -1, g_gemm_forced = -2;           // environment switches, parsed once (ln3d_reload_env() re-reads them)
-static int gemm_abl() {
-  if (g_gemm_abl < 0) { const char* e = getenv("LN3D_GEMM_ABL"); g_gemm_abl = e ? atoi(e) : 0; }
-  return g_gemm_abl;
-}
+static int g_gemm_forced = -2;           // environment switch, parsed once (ln3d_reload_env() re-reads it)
 static int forced_cfg() {
   if (g_gemm_forced == -2) {
     const char* e = getenv("LN3D_GEMM_TILE");
@@ -1382,9 +1040,9 @@ static int forced_cfg() {
   }
   return g_gemm_forced;
 }
-extern "C" void ln3d_gemm_reload_env(void) { g_gemm_abl = -1; g_gemm_forced = -2; }
+extern "C" void ln3d_gemm_reload_env(void) { g_gemm_forced = -2; }
 static int pick_cfg(int M, int N, bool head_aligned = false) {
-  if (forced_cfg() >= 0 && forced_cfg() != 15) return forced_cfg();      // x15 = the persistent kernel where legal, the automatic choice elsewhere
+  if (forced_cfg() >= 0) return forced_cfg();
   if (!(M >= 1536 && N >= 128)) return 0;
   static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
                                                                {8, 128, 384, 0.945f}};
@@ -1408,30 +1066,6 @@ static int pick_cfg(int M, int N, bool head_aligned = false) {
   return best;
 }
 
-// The persistent deferred-store kernel (gemm_bf16_pring_kernel) takes bf16-output problems made of full 256x192 tiles with at
-// least two tiles per CU; everything else stays on the one-tile-per-workgroup kernels.  LN3D_GEMM_TILE=x15 forces it where it is
-// legal, any other forced tile disables it (A/B runs).
-static bool pring_eligible(const ln3d_gemm_args* a) {
-  const int e = a->epilogue;
-  if (!(e == LN3D_EPI_BF16 || e == LN3D_EPI_GELU_ERF || e == LN3D_EPI_GELU_TANH || e == LN3D_EPI_SILU || e == LN3D_EPI_QUICK_GELU ||
-        e == LN3D_EPI_HEADS))
-    return false;
-  if (forced_cfg() >= 0 && forced_cfg() != 15) return false;
-  if ((a->N % 256) != 0 || (a->M % 192) != 0 || a->K < 320) return false;
-  const int64_t tiles = (int64_t)(a->N / 256) * (a->M / 192);
-  if (forced_cfg() != 15 && tiles < 2 * (int64_t)num_cus()) return false;
-  if (((uintptr_t)a->out0 & 15) != 0 || (a->bias && ((uintptr_t)a->bias & 15) != 0)) return false;
-  if (e == LN3D_EPI_HEADS) {
-    const int pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
-    if (a->head_dim != 64 || pad != 64 || a->heads <= 0 || ((a->heads * 64) % 256) != 0 || (a->N % (a->heads * 64)) != 0 || a->N > 3 * a->heads * 64)
-      return false;
-    if (a->tokens <= 0 || (a->tokens % 32) != 0 || (a->M % a->tokens) != 0 || (a->tok_pad % 8) != 0) return false;
-    if (!a->out1 || (a->N > 2 * a->heads * 64 && !a->out2)) return false;
-    if (((uintptr_t)a->out1 & 15) != 0 || ((uintptr_t)a->out2 & 15) != 0) return false;
-  } else if ((a->ldo % 8) != 0) return false;
-  return true;
-}
-
 extern "C" int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int head_dim_pad) {
   if (head_dim_pad <= 0) head_dim_pad = head_dim;
   if (!(head_dim == 64 && head_dim_pad == 64 && tokens > 0 && (tokens & 31) == 0 && (M % tokens) == 0 && (N % 64) == 0)) return 0;
@@ -1453,23 +1087,9 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.transpose_mask = a->transpose_mask;
   p.head_dim_pad = a->head_dim_pad > 0 ? a->head_dim_pad : a->head_dim;
   p.ctx_keys = a->ctx_keys; p.ctx_pad = a->ctx_pad; p.ctx_scale_log2 = a->ctx_scale * 1.4426950408889634f;
-  p.abl = gemm_abl();
   p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
   p.rb = a->epilogue == LN3D_EPI_GATE_RES ? a->res_bias : nullptr; p.rb_ld = a->res_bias_ld;
   hipStream_t s = (hipStream_t)stream;
-  if (pring_eligible(a)) {
-    switch (a->epilogue) {
-      case LN3D_EPI_BF16: return launch_pring<LN3D_EPI_BF16>(p, s);
-      case LN3D_EPI_GELU_ERF: return launch_pring<LN3D_EPI_GELU_ERF>(p, s);
-      case LN3D_EPI_GELU_TANH: return launch_pring<LN3D_EPI_GELU_TANH>(p, s);
-      case LN3D_EPI_SILU: return launch_pring<LN3D_EPI_SILU>(p, s);
-      case LN3D_EPI_QUICK_GELU: return launch_pring<LN3D_EPI_QUICK_GELU>(p, s);
-      case LN3D_EPI_HEADS:
-        if (a->tok_pad < a->tokens) return LN3D_ERR_BAD_ARG;
-        return launch_pring<LN3D_EPI_HEADS>(p, s);
-      default: break;
-    }
-  }
   const int cfg = pick_cfg(a->M, a->N, a->epilogue == LN3D_EPI_HEADS && a->head_dim == 64 && a->head_dim_pad <= 64);
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   };
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  printf("LN3D_RING_D1=%d LN3D_RING_ABL=%d LN3D_GEMM_ABL=%s\n", LN3D_RING_D1, LN3D_RING_ABL, getenv("LN3D_GEMM_ABL") ? getenv("LN3D_GEMM_ABL") : "-");
+  printf("LN3D_RING_D1=%d LN3D_RING_ABL=%d \n", LN3D_RING_D1, LN3D_RING_ABL);
   for (const Case& c : cases) {
     if (!strstr(c.name, filt)) continue;
     if (c.tile) setenv("LN3D_GEMM_TILE", c.tile, 1); else unsetenv("LN3D_GEMM_TILE");
