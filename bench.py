@@ -347,6 +347,8 @@ def main():
     ap.add_argument("--dec-arch", default="DiT2-L/2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--dist", action="store_true",
+                    help="go through torch.distributed.run + an RCCL process group even with --gpus 1 (the N-GPU code path on one GPU)")
     args = ap.parse_args()
     i23d = args.workload == "i23d"
     args.batch = args.batch or (32 if i23d else 8)
@@ -354,7 +356,7 @@ def main():
     args.views = args.views or (24 if i23d else 40)
     args.arch = args.arch or ("DiT-PixArt-L/2" if i23d else "DiT-L/2")
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.dist) and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
     from ln3diff_amd import parallel
     from ln3diff_amd.pipeline import T23DPipeline, FlowMatchingEngine, render_pairs
@@ -376,9 +378,17 @@ def main():
         dit = build_i23d(dev, args.arch, fill=(rank == 0), golden_weights=True)
     else:
         dit, dec = build_models(dev, args.arch, args.dec_arch, fill=(rank == 0), golden_weights=True)
-    if world > 1:
-        parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] +
-                                [b for b in dec.buffers()], src=0)
+    # every collective of the run is exercised before the timed region: an all_reduce of ones (how many ranks RCCL reaches),
+    # the flat weight broadcast (timed separately: start-up, not part of a step)
+    seen = parallel.ranks_seen()
+    if seen != world:
+        raise SystemExit("bench.py: all_reduce of ones returned %d on a %d-rank launch" % (seen, world))
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
+    parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] +
+                            [b for b in dec.buffers()], src=0)
+    torch.cuda.synchronize()
+    bcast_ms = parallel.max_over_ranks((time.perf_counter() - t_b) * 1e3)
     B, Bt = args.batch, args.batch * world
     g = torch.Generator(device=dev).manual_seed(42 if i23d else 41)            # global seed, full batch, then sliced per rank
     z_all = torch.randn(Bt, 12, 32, 32, device=dev, generator=g)
@@ -463,6 +473,7 @@ def main():
             "config": {"workload": wl, "global_batch": Bt, "views": args.views, "res": args.res,
                        "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
             "finite": ok,
+            "ranks_seen": seen, "collectives": parallel.collective_info(), "bcast_ms": round(bcast_ms, 2),
             "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps),
         }
         if not args.no_probes:
@@ -485,7 +496,16 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B, i23d=i23d)
         print(json.dumps(rec), flush=True)
     parallel.barrier()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:          # a failing rank must take the job down (non-zero exit -> the launcher kills the others), never leave them waiting in a collective
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(e.code if isinstance(e, SystemExit) and isinstance(e.code, int) else 1)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -113,14 +114,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(
 // hipFuncSetAttribute applies to the CURRENT device: remembered per (kernel instantiation, device) so that a process driving several
 // GPUs sets it on each of them (one process per GPU is the deployment, but the library must not depend on it)
 struct AttrOnce {
-  unsigned long long done = 0;
+  std::atomic<unsigned long long> done{0};
   bool need() {
     int d = 0;
-    (void)hipGetDevice(&d);
-    const unsigned long long bit = 1ull << (d & 63);
-    if (done & bit) return false;
-    done |= bit;
-    return true;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;      // unknown / high device id: set the attribute every time
+    const unsigned long long bit = 1ull << d;
+    return (done.fetch_or(bit) & bit) == 0;                                    // two host threads racing here: at worst both set it
   }
 };
 

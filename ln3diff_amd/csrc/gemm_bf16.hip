@@ -1077,6 +1077,13 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   if (!a || !a->X || !a->W || !a->out0) return LN3D_ERR_BAD_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0 || (a->N % 4) != 0) return LN3D_ERR_BAD_ARG;
   if ((a->ldx % 8) != 0 || (a->ldw % 8) != 0) return LN3D_ERR_BAD_ARG;
+  if (a->epilogue == LN3D_EPI_GATE_RES) {
+    // the epilogue reads float4 quads at gate / res_bias + sample * ld + feature: 16-byte aligned rows, and a per-sample row needs
+    // gate_rows (rows per sample) - with it left at 0 every TOKEN would index a row of a [samples, N] buffer
+    if (a->gate && ((a->gate_ld % 4) != 0 || ((uintptr_t)a->gate & 15) != 0)) return LN3D_ERR_BAD_ARG;
+    if (a->res_bias && ((a->res_bias_ld % 4) != 0 || ((uintptr_t)a->res_bias & 15) != 0)) return LN3D_ERR_BAD_ARG;
+    if ((a->gate || a->res_bias) && a->gate_rows <= 0) return LN3D_ERR_BAD_ARG;
+  }
   GemmP p;
   p.X = (const bf16_t*)a->X; p.W = (const bf16_t*)a->W; p.bias = a->bias;
   p.ldx = a->ldx; p.ldw = a->ldw; p.ldo = a->ldo;

@@ -305,8 +305,17 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
             return None
         fused = qk and ops.heads_norm_fusable(Bn * Ld, 3 * H * Dp, Ld, Dh, Dp)    # small prompts batches: norm in a second pass
         dev = cc['dino'].device
-        sa_k = torch.zeros(self.depth, Bn, H, npad, Dp, dtype=torch.bfloat16, device=dev)
-        sa_vt = torch.zeros(self.depth, Bn, H, Dp, npad, dtype=torch.bfloat16, device=dev)
+        # The prepared context `cc` OWNS these buffers for its lifetime (every live context holds its own copy): the cache is taken
+        # only while it fits a third of the device memory that is free right now, and an allocation failure falls back to the
+        # full projection as well (several prepared prompts, or a smaller-HBM part, must not die in forward()).
+        need = 2 * self.depth * Bn * H * npad * Dp * 2
+        try:
+            if dev.type == 'cuda' and need > torch.cuda.mem_get_info(dev)[0] // 3:
+                return None
+            sa_k = torch.zeros(self.depth, Bn, H, npad, Dp, dtype=torch.bfloat16, device=dev)
+            sa_vt = torch.zeros(self.depth, Bn, H, Dp, npad, dtype=torch.bfloat16, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            return None
         qs = ws.get('sa_q', (Bn, H, npad, Dp), torch.bfloat16, zero=True)
         rows = cc['dino'].reshape(Bn * Ld, D)
         for i, q in enumerate(P['blocks']):

@@ -74,7 +74,7 @@ def create_argparser(objaverse=True):
         ode_method='dopri5', use_ddim=False, clip_denoised=False, image_size=128, num_views=40 if objaverse else 24, export_mesh=False,
         mesh_grid=192, mesh_thres=10.0, logdir='./logs/sample', resume_checkpoint='', ddpm_model_path='', rec_model_path='',
         cond_path='', pose_path='', seed=41 if objaverse else 0, context_dim=768, learn_sigma=False, denoise_in_channels=4,
-        diffusion_input_size=32, roll_out=True, prompt='' if objaverse else 'a red chair', cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
+        diffusion_input_size=32, roll_out=True, prompt=None, cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
         mv_input=False, num_mv_views=4, clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
         overwrite_diff_inp_size='', create_controlnet=False)
     d.update(_IGNORED_DEFAULTS)
@@ -196,7 +196,8 @@ def load_conditioning(args, dev, objaverse=True):
     if args.cond_path:
         raw = torch.load(args.cond_path) if args.cond_path.endswith('.pt') else dict(np.load(args.cond_path))
         return {k: torch.as_tensor(v).float() for k, v in raw.items()}, f'tensors from {args.cond_path}'
-    default_prompt = '' if objaverse else 'a red chair'
+    # --prompt defaults to None: "not given" (the reference scripts' defaults - '' / 'a red chair' - then only label the synthetic
+    # run); ANY explicit --prompt, also one equal to a script default, must be encoded or is refused
     if args.image_path:
         if not args.i23d:
             raise SystemExit("--image_path conditions the I23D models: pass --i23d true (and --trainer_name flow_matching)")
@@ -213,7 +214,7 @@ def load_conditioning(args, dev, objaverse=True):
         img = _read_image(args.image_path).to(dev)
         c = I23DConditioner(clip.to(dev), dino.to(dev))(img)
         return {k: v.float().cpu() for k, v in c.items()}, f'I23DConditioner({args.image_path})'
-    if args.prompt and args.prompt != default_prompt or (args.prompt and args.clip_checkpoint):
+    if args.prompt is not None:
         if args.i23d:
             raise SystemExit("--prompt conditions the T23D models; the I23D models take --image_path / --cond_path")
         if not args.clip_checkpoint:
@@ -286,7 +287,18 @@ def run(args, objaverse=None):
     dit, ae, dec, weights_from = build_models(args, dev, rank)
     parallel.broadcast_flat([p.data for p in dit.parameters()] + [p.data for p in dec.parameters()] + list(dec.buffers()), src=0)
 
-    cond_all, cond_src = load_conditioning(args, dev, objaverse)
+    # conditioning is produced ONCE, on rank 0 (checkpoint loads, image / prompt encoding), and broadcast; a failure there is
+    # broadcast too, so that every rank leaves with the same message instead of waiting in the next collective
+    res = [None]
+    if rank == 0:
+        try:
+            res = [load_conditioning(args, dev, objaverse) + (None,)]
+        except BaseException as e:
+            res = [(None, None, f"{type(e).__name__}: {e}")]
+    res = parallel.broadcast_object(res[0], src=0)
+    if res[2] is not None:
+        raise SystemExit("conditioning failed on rank 0: " + res[2])
+    cond_all, cond_src = res[0], res[1]
     if rank == 0:
         meta = dict(vars(args), conditioning=cond_src, weights={k: (v or 'synthetic') for k, v in weights_from.items()})
         with open(os.path.join(args.logdir, 'args.json'), 'w') as f:
@@ -338,6 +350,7 @@ def run(args, objaverse=None):
 
     lat_all, frames, pairs = parallel.sharded_step(sample_fn, render_fn, Bt, V, rank, world)
     lo, hi = parallel.shard_range(Bt, rank, world)
+    mesh_err = None
     if args.export_mesh and hi > lo:
         # meshes go with the SAMPLE shard; the file name carries the global sample id from the start (r2 wrote `sample{local}.obj`
         # on every rank and renamed afterwards: two ranks raced on the same names)
@@ -351,13 +364,13 @@ def run(args, objaverse=None):
             path = os.path.join(args.logdir, f'mesh_sample{lo + i}.obj')
             mesh_from_grid(ae.decoder, d, grid['sigma'][i], args.mesh_grid, args.mesh_thres, sample_index=i, path=path)
             if not os.path.exists(path):
-                raise RuntimeError(f"mesh export of sample {lo + i} produced no file at {path}")
-    # frames_rank{r}.npy: [samples of this rank, V, 3, R, R] when the rank's pairs are whole samples (always with >= 1 sample per
-    # rank), else the flat pair list [P, 3, R, R]; pairs_rank{r}.npy names the (sample, view) of every frame either way
-    whole = all(v0 == 0 and v1 == V for _, v0, v1 in pairs)
-    shp = (lambda t: t.reshape(len(pairs), V, *t.shape[1:])) if (whole and pairs) else (lambda t: t)
-    np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), shp(frames['image_raw']).cpu().numpy())
-    np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), shp(frames['image_depth']).cpu().numpy())
+                mesh_err = f"mesh export of sample {lo + i} produced no file at {path}"
+                break
+    parallel.agree_ok(mesh_err)                               # collective: every rank raises when any rank failed
+    # frames_rank{r}.npy / depth_rank{r}.npy: ALWAYS the flat pair list [P, 3 | 1, R, R]; pairs_rank{r}.npy = the (sample, view) of
+    # every frame (one layout whatever the sharding: r3 switched between [S, V, ...] and [P, ...])
+    np.save(os.path.join(args.logdir, f'frames_rank{rank}.npy'), frames['image_raw'].cpu().numpy())
+    np.save(os.path.join(args.logdir, f'depth_rank{rank}.npy'), frames['image_depth'].cpu().numpy())
     np.save(os.path.join(args.logdir, f'pairs_rank{rank}.npy'), frames['pair_index'].cpu().numpy())      # [P, 2] = (sample, view) of every frame
     np.save(os.path.join(args.logdir, f'latent_rank{rank}.npy'), lat_all[lo:hi].cpu().numpy())
     fr = frames['image_raw'].cpu().numpy()

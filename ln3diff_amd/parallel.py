@@ -20,25 +20,63 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def setup_dist(backend=None):
-    """env:// rendezvous (reference guided_diffusion/dist_util.py:57-73)."""
+PG_TIMEOUT_S = 120      # the sampling path has no long collective: a rank that died must surface as an error within minutes
+                        # (the reference waits 15 h: guided_diffusion/dist_util.py:68)
+
+
+def launched_by_torchrun():
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+
+
+def setup_dist(backend=None, timeout_s=None):
+    """env:// rendezvous (reference guided_diffusion/dist_util.py:57-73).  The process group is created whenever the process was
+    started by a launcher (RANK / WORLD_SIZE / MASTER_ADDR set) - also with ONE rank, so that a single-GPU box exercises the same
+    RCCL initialisation, broadcast, all_gather and all_reduce calls as an 8-GPU node - and with a short timeout."""
+    import datetime
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or launched_by_torchrun()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://",
+                                timeout=datetime.timedelta(seconds=timeout_s or PG_TIMEOUT_S))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     return rank, local_rank, world
 
 
+def ranks_seen(dev=None):
+    """all_reduce of ones: how many ranks the collective layer actually reaches (1 without a process group)."""
+    if not dist.is_initialized():
+        return 1
+    if dev is None:
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
+def collective_info():
+    """What carries the collectives: backend name and, for nccl (= RCCL on ROCm), the library version."""
+    if not dist.is_initialized():
+        return {"backend": None}
+    info = {"backend": dist.get_backend()}
+    if info["backend"] == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:                     # the version query is informational only
+            info["rccl_version"] = "unknown (%s)" % type(e).__name__
+    return info
+
+
 def broadcast_flat(tensors, src=0):
-    """Broadcast a list of same-device tensors as ONE flat buffer per dtype."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    """Broadcast a list of same-device tensors as ONE flat buffer per dtype (also with one rank when a process group exists:
+    the single-GPU launcher path runs the same RCCL calls as a node)."""
+    if not dist.is_initialized():
         return
     by_dtype = {}
     for t in tensors:
@@ -98,7 +136,7 @@ def all_gather_cat(t):
     """Concatenate every rank's rows (dim 0).  Shards may be ragged or EMPTY (fewer samples than ranks): the row counts are
     gathered first, every rank pads to the largest shard, and the padding is dropped after the collective.  All ranks must
     call it (it is a collective) - also the ones whose shard is empty."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return t
     world = dist.get_world_size()
     n_loc = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
@@ -116,14 +154,43 @@ def all_gather_cat(t):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(x):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return x
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def broadcast_object(obj, src=0):
+    """A picklable object from `src` to every rank (conditioning tensors, error strings); identity without a process group."""
+    if not dist.is_initialized():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def agree_ok(err):
+    """Collective: `err` is None or this rank's error message.  Raises RuntimeError on EVERY rank when any rank reported one - a
+    failure on one rank must not leave the others waiting in their next collective."""
+    if not dist.is_initialized():
+        if err is not None:
+            raise RuntimeError(err)
+        return
+    errs = [None] * dist.get_world_size()
+    dist.all_gather_object(errs, err)
+    bad = [f"rank {r}: {e}" for r, e in enumerate(errs) if e is not None]
+    if bad:
+        raise RuntimeError("; ".join(bad))
+
+
+def shutdown():
+    """Tear the process group down (quiet exit of launcher-started runs)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()

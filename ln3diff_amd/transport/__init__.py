@@ -177,11 +177,12 @@ _DP_MID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -26
            187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
 
 
-def dopri5_next_step(dt, ratio, accepted, safety=0.9, ifactor=10.0, dfactor=0.2):
-    """torchdiffeq's _optimal_step_size (order 5)."""
+def dopri5_next_step(dt, ratio, safety=0.9, ifactor=10.0, dfactor=0.2):
+    """torchdiffeq's _optimal_step_size (order 5): the lower clamp is lifted to 1 only for error_ratio < 1 (a step with ratio == 1
+    exactly is accepted - `error_ratio <= 1` - but may still shrink by the safety factor)."""
     if ratio == 0:
         return dt * ifactor
-    return dt * min(ifactor, max(safety / ratio ** 0.2, 1.0 if accepted else dfactor))
+    return dt * min(ifactor, max(safety / ratio ** 0.2, 1.0 if ratio < 1.0 else dfactor))
 
 
 def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
@@ -256,7 +257,7 @@ def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
                     t0, t1 = ta, ta + dt
                     y.copy_(y1b)
                     k[0] = k[6]
-                dt = dopri5_next_step(dt, ratio, ok)
+                dt = dopri5_next_step(dt, ratio)
             xq = (t_out - t0) / (t1 - t0)
             yo = torch.empty_like(y)
             ops.lincomb(None, [y0i, f0i, cc, cb, ca], [1.0, xq * dti, xq ** 2, xq ** 3, xq ** 4], yo)     # _interp_evaluate

@@ -285,7 +285,7 @@ def flow_ode_dopri5(model_fn, x, num_steps=50, atol=1e-6, rtol=1e-3, stats=None,
             if ratio == 0:
                 dt = dt * 10.0
             else:
-                dt = dt * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ok else 0.2))
+                dt = dt * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))      # dfactor -> 1 only for ratio < 1 (torchdiffeq _optimal_step_size)
         xq = (t_out - t0) / (t1 - t0)
         out = coef[0] + xq * coef[1] + xq ** 2 * coef[2] + xq ** 3 * coef[3] + xq ** 4 * coef[4]
     if stats is not None:

@@ -64,3 +64,20 @@ def test_host_queries(hip_lib):
     # the fused qk-norm epilogue needs head-aligned tiles: 64-wide heads yes, 72-in-128 padded heads no
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3072, 768, 64, 64) == 1
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3 * 16 * 128, 768, 72, 128) == 0
+
+
+def test_gate_residual_row_arguments_are_validated(hip_lib):
+    """the GATE_RES epilogue reads float4 quads at gate / res_bias + (row / gate_rows) * ld + feature - a leading dimension
+    that is not a multiple of 4, a misaligned pointer or gate_rows left at 0 next to a per-sample buffer is a bad argument, not an
+    out-of-bounds read.  Validation happens before anything touches the device (fake, never dereferenced addresses)."""
+    from ln3diff_amd._lib import GemmArgs, EPI_GATE_RES
+    base = dict(X=0x10000, ldx=64, W=0x20000, ldw=64, M=192, N=256, K=64, epilogue=EPI_GATE_RES, out0=0x30000, ldo=256)
+    bad = [dict(gate=0x40000, gate_rows=96, gate_ld=258),              # ld % 4
+           dict(gate=0x40004, gate_rows=96, gate_ld=256),              # pointer not 16-byte aligned
+           dict(gate=0x40000, gate_rows=0, gate_ld=256),               # rows per sample missing
+           dict(res_bias=0x50000, res_bias_ld=255, gate_rows=96),
+           dict(res_bias=0x50008, res_bias_ld=256, gate_rows=96),
+           dict(res_bias=0x50000, res_bias_ld=256, gate_rows=0)]
+    for extra in bad:
+        a = GemmArgs(**dict(base, **extra))
+        assert hip_lib.ln3d_gemm_bf16(C.byref(a), None) == -1, extra

@@ -84,6 +84,9 @@ def test_conditioning_is_never_silently_synthetic():
     assert src == 'synthetic' and c['crossattn'].shape == (1, 77, 768)
     c, src = load_conditioning(_args(False), 'cpu', False)              # the second script's DEFAULT prompt: allowed, labelled
     assert src == 'synthetic'
+    with pytest.raises(SystemExit) as e:          # an EXPLICIT prompt equal to the reference script's default is still a prompt
+        load_conditioning(_args(False, "--prompt", "a red chair"), 'cpu', False)
+    assert "--clip_checkpoint" in str(e.value)
     for flags, msg in ((("--prompt", "a blue car"), "--clip_checkpoint"),
                        (("--i23d", "true", "--image_path", "/tmp/x.npy"), "--clip_checkpoint"),
                        (("--image_path", "/tmp/x.npy"), "--i23d"),

@@ -27,7 +27,8 @@ def test_entry_points_run(hip_lib, tmp_path, objaverse, flags):
     lat = run(args)
     assert lat.shape == (2, 12, 32, 32) and torch.isfinite(lat).all()
     frames = np.load(tmp_path / "frames_rank0.npy")
-    assert frames.shape == (2, 2, 3, 32, 32) and np.isfinite(frames).all()
+    assert frames.shape == (4, 3, 32, 32) and np.isfinite(frames).all()            # flat (sample, view) pair list, pairs_rank0.npy names them
+    assert np.load(tmp_path / "pairs_rank0.npy").tolist() == [[0, 0], [0, 1], [1, 0], [1, 1]]
     assert np.array_equal(np.load(tmp_path / "latents_all.npy"), lat.cpu().numpy())
     assert os.path.exists(tmp_path / "sample1_view0.ppm") and os.path.exists(tmp_path / "args.json")
     if args.export_mesh:
@@ -46,7 +47,7 @@ def test_config3_xl2_text_cond_end_to_end(hip_lib, tmp_path):
                                               f"--image_size 64 --num_views 3 --logdir {tmp_path}").split())
     lat = run(args)
     assert lat.shape == (2, 12, 32, 32) and torch.isfinite(lat).all()
-    assert np.load(tmp_path / "frames_rank0.npy").shape == (2, 3, 3, 64, 64)
+    assert np.load(tmp_path / "frames_rank0.npy").shape == (6, 3, 64, 64)
 
 
 def test_config4_i23d_512_24cams_mesh_end_to_end(hip_lib, tmp_path):
@@ -60,6 +61,6 @@ def test_config4_i23d_512_24cams_mesh_end_to_end(hip_lib, tmp_path):
     frames = np.load(tmp_path / "frames_rank0.npy")
     depth = np.load(tmp_path / "depth_rank0.npy")
     print('config4 frames', frames.shape, 'finite', bool(np.isfinite(frames).all()), 'absmax', float(np.nanmax(np.abs(frames))), 'latent std', float(lat.std()))
-    assert frames.shape == (1, 24, 3, 512, 512) and np.isfinite(frames).all() and np.abs(frames).max() <= 1.0 + 2e-3
-    assert depth.shape == (1, 24, 1, 512, 512) and np.isfinite(depth).all()
+    assert frames.shape == (24, 3, 512, 512) and np.isfinite(frames).all() and np.abs(frames).max() <= 1.0 + 2e-3
+    assert depth.shape == (24, 1, 512, 512) and np.isfinite(depth).all()
     assert os.path.exists(tmp_path / "mesh_sample0.obj")

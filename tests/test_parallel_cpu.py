@@ -49,6 +49,7 @@ def _worker(rank, world, port, q):
         got = parallel.all_gather_cat(zt[lo:hi] * 2.0)
         ok_g = ok_g and got.shape[0] == total and torch.equal(got, zt * 2.0)
     t = parallel.max_over_ranks(1.0 + rank)
+    ok_g = ok_g and parallel.ranks_seen() == world and parallel.collective_info()["backend"] == "gloo"
     parallel.barrier()
     q.put((rank, ok_b, ok_g, t))
 
@@ -66,6 +67,69 @@ def test_world2_gloo_broadcast_shard_gather():
         assert p.exitcode == 0
     for rank, ok_b, ok_g, t in res:
         assert ok_b and ok_g and t == 2.0, (rank, ok_b, ok_g, t)
+
+
+def _worker_world1(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from ln3diff_amd import parallel
+    r, lr, w = parallel.setup_dist('gloo')
+    ok = (r, w) == (0, 1) and dist.is_initialized()                    # launcher environment: a process group even with one rank
+    ts = [torch.arange(6.0).reshape(2, 3), torch.ones(4, dtype=torch.bfloat16)]
+    ref = [t.clone() for t in ts]
+    parallel.broadcast_flat(ts, src=0)
+    ok = ok and all(torch.equal(a, b) for a, b in zip(ts, ref))
+    z = torch.randn(3, 12, 4, 4)
+    ok = ok and torch.equal(parallel.all_gather_cat(z), z) and parallel.all_gather_cat(z[:0]).shape[0] == 0
+    ok = ok and parallel.ranks_seen() == 1 and parallel.max_over_ranks(2.5) == 2.5
+    parallel.barrier()
+    q.put(ok)
+
+
+def test_world1_process_group_runs_the_same_collectives():
+    """r4: a launcher-started single rank (driver: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`) creates a process
+    group and goes through every collective of the N-rank path (gloo here, RCCL in tests/test_dist_gpu.py)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
+def _worker_dies(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import time
+    from ln3diff_amd import parallel
+    parallel.setup_dist('gloo', timeout_s=8)
+    parallel.barrier()
+    if rank == 1:
+        os._exit(3)                                  # a rank that dies between collectives
+    t0 = time.time()
+    try:
+        parallel.all_gather_cat(torch.zeros(2, 3))
+        q.put(('no error', time.time() - t0))
+    except Exception as e:
+        q.put((type(e).__name__, time.time() - t0))
+
+
+def test_dead_rank_surfaces_as_an_error_not_a_hang():
+    """The process group carries a short timeout (parallel.PG_TIMEOUT_S = 120 s in production, 8 s here; the reference sets 15 h,
+    guided_diffusion/dist_util.py:68): the survivor of a rank that died gets an exception from its next collective."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_dies, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    what, dt = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+    assert what != 'no error' and dt < 60, (what, dt)
+    assert ps[1].exitcode == 3
 
 
 def _stub_sample_fn(z_all):
