@@ -109,6 +109,10 @@ typedef struct {
   int64_t ldo;
   float scale;
   int causal;              /* 1: query i attends keys <= i (CLIP text tower; Dh 64 and Nk <= 128 only); 0: full attention */
+  int Dh_true;             /* ABI 8: true head size when Q / K / Vt rows are stored zero-padded to Dh (0 or Dh = not padded).  72 with
+                            * Dh 128 (DiT-XL/2, dit/dit_trilatent.py:272: hidden 1152 / 16 heads): the products skip the padding and
+                            * O is written COMPACT, O[b, q, h*Dh_true + d] with ldo = H*Dh_true, so the projection behind it
+                            * contracts over H*Dh_true.  Other values: LN3D_ERR_UNSUPPORTED. */
 } ln3d_attn_args;
 int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream);
 

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp),
                 ("B", i32), ("H", i32), ("Nq", i32), ("Nq_pad", i32), ("Nk", i32), ("Nk_pad", i32),
-                ("Dh", i32), ("ldo", i64), ("scale", f32), ("causal", i32)]
+                ("Dh", i32), ("ldo", i64), ("scale", f32), ("causal", i32), ("Dh_true", i32)]
 
 
 class NormArgs(C.Structure):
@@ -85,7 +85,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 7
+    assert L.ln3d_abi_version() == 8
     return True
 
 

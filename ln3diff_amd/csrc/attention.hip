@@ -44,14 +44,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 
-template <int DH, int OCC>
+// DT = true head size when the heads are stored zero-padded to DH (DiT-XL/2: 72 in 128-wide rows, r4): the S^T products run over
+// ceil(DT / 16) k-steps and the PV products over ceil(DT / 32) blocks of output rows instead of DH / 16 and DH / 32 (5 + 3 of
+// 8 + 4 for 72: the padding contributes exact zeros), and O is written COMPACT, DT dims per head (row stride ldo = H * DT), so the
+// projection GEMM behind it contracts over H * DT instead of H * DH.  K / V^T tiles are still fetched whole (the DMA map and
+// its counted waits stay those of the DH-wide layout).
+template <int DH, int OCC, int DT = DH>
 __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   constexpr int NST = DH == 64 ? 4 : 3;           // ring depth
   constexpr int KROWB = DH * 2;                   // K tile row bytes
   constexpr int KTILE = KVB * KROWB;
   constexpr int VTILE = DH * 128;                 // V^T tile: DH rows x 64 keys
   constexpr int STAGEB = KTILE + VTILE;
-  constexpr int NDS = DH / 16, NDT = DH / 32;
+  constexpr int NDS = (DT + 15) / 16, NDT = (DT + 31) / 32;
+  static_assert(DT <= DH && DT % 8 == 0, "true head size: a multiple of 8 within the stored row");
   constexpr int LPW = DH / 64;                    // DMA instructions per wave per tile (K and V^T each)
   constexpr int KCH = DH / 8;                     // 16-B chunks per K row (8 or 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,8 +65,16 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * 256 + wid * 32;
+  // block -> (head, query block): the query blocks of a head run on ONE XCD (block b runs on XCD b % 8), next to each other in
+  // dispatch order, so that the head's K / V^T stream is fetched into that XCD's L2 once (r4; a (query block, head) grid spread
+  // them over three XCDs)
+  int bh, qblk;
+  {
+    const int nqb_ = (p.Nq + 255) / 256, BH_ = p.B * p.H, b_ = blockIdx.x;
+    if ((BH_ & 7) == 0) { const int xcd = b_ & 7, slot = b_ >> 3; bh = (slot / nqb_) * 8 + xcd; qblk = slot % nqb_; }
+    else { bh = b_ / nqb_; qblk = b_ % nqb_; }
+  }
+  const int q0 = qblk * 256 + wid * 32;
 
   const bf16_t* Qg = p.Q + (int64_t)bh * p.Nq_pad * DH;
   const bf16_t* Kg = p.K + (int64_t)bh * p.Nk_pad * DH;
@@ -224,15 +238,18 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     const int b = bh / p.H, h = bh - b * p.H;
     const int rrow = lane >> 4, rc = lane & 15;
 #pragma unroll
-    for (int dp = 0; dp < DH / 64; ++dp) {
+    for (int dp = 0; dp < (DT + 63) / 64; ++dp) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = ii * 8 + 2 * g + hi;
           const int dt = 2 * dp + ii;
-          *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
-              make_float4(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          if (dt < NDT) {                            // compile-time after unrolling
+            const int dc = dt < NDT ? dt : 0;
+            *reinterpret_cast<float4*>(stg + l31 * 256 + ((c ^ (l31 & 15)) << 4)) =
+                make_float4(oacc[dc][4 * g + 0] * inv, oacc[dc][4 * g + 1] * inv, oacc[dc][4 * g + 2] * inv, oacc[dc][4 * g + 3] * inv);
+          }
         }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {               // 8 dims per lane: 16-byte stores, 8 lanes per 128-byte row
@@ -240,10 +257,10 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
         const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
         const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
         const int q = q0 + row;
-        if (q < p.Nq) {
+        if (q < p.Nq && dp * 64 + 8 * c8 < DT) {     // compact heads: only the true dims leave
           uint4 o;
           o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w); o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
-          *reinterpret_cast<uint4*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DH + dp * 64 + 8 * c8) = o;
+          *reinterpret_cast<uint4*>(p.O + ((int64_t)b * p.Nq + q) * p.ldo + h * DT + dp * 64 + 8 * c8) = o;
         }
       }
     }
@@ -1261,17 +1278,17 @@ static int launch_attn_short(const AttnP& p, hipStream_t s) {
   return ln3d_check_launch();
 }
 
-template <int DH, int OCC>
+template <int DH, int OCC, int DT = DH>
 static int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NST = DH == 64 ? 4 : 3;
   constexpr int LDS = NST * (KVB * DH * 2 + DH * 128);
   static AttrOnce attr_once;
   if (attr_once.need()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH, OCC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH, OCC, DT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
-  dim3 grid((p.Nq + 255) / 256, p.B * p.H);
-  hipLaunchKernelGGL((attn_kernel<DH, OCC>), grid, dim3(512), LDS, s, p);
+  dim3 grid(((p.Nq + 255) / 256) * p.B * p.H);
+  hipLaunchKernelGGL((attn_kernel<DH, OCC, DT>), grid, dim3(512), LDS, s, p);
   return ln3d_check_launch();
 }
 
@@ -1336,6 +1353,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // causal masking exists in the short-sequence kernel only (its one user is the 77-token CLIP text tower)
   if (a->causal && !(a->Dh == 64 && a->Nk <= 128)) return LN3D_ERR_UNSUPPORTED;
+  if (a->Dh_true != 0 && a->Dh_true != a->Dh && a->Dh != 128) return LN3D_ERR_UNSUPPORTED;   // compact heads: the padded-128 kernel only
   if (a->Dh == 64) {
     // The short-sequence kernel serves the causal text tower; for the non-causal 77-key cross-attention it measures 2 us
     // faster in isolation but slower inside the sampling loop than the ring kernel (and the DiT runs that attention inside
@@ -1351,7 +1369,11 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
     }
     return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
   }
-  if (a->Dh == 128) return launch_attn<128, 2>(p, s);
+  if (a->Dh == 128) {
+    if (a->Dh_true == 0 || a->Dh_true == 128) return launch_attn<128, 2>(p, s);
+    if (a->Dh_true == 72) return launch_attn<128, 2, 72>(p, s);           // DiT-XL/2
+    return LN3D_ERR_UNSUPPORTED;
+  }
   return LN3D_ERR_UNSUPPORTED;
 }
 

@@ -13,232 +13,107 @@ struct NormP {
   const float* shift_table; const float* scale_table; int rows_in, rows_out;
 };
 
+// One wavefront per row.  Every lane owns 8 consecutive features per 512-column chunk: two 16-byte loads and ONE 16-byte bf16 store
+// (8-byte global accesses run at 0.5-0.7x the 16-byte rate on gfx950); a last partial chunk (D = 1152: 128 columns) is carried by
+// its first D % 512 / 8 lanes.  r4: this is the only norm + modulate kernel (r1's float2 and r2's float4 variants served the widths
+// that are not multiples of 512 - DiT-XL/2's 1152 ran 1.6x slower per byte than the 1024-wide rows).  One row per wave: r3 measured
+// 14.0 / 17.2 / 20.4 us at 1 / 2 / 4 rows per wave (12288 x 1024).
 __global__ __launch_bounds__(256) void norm_modulate_kernel(NormP p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
-  const int nv = p.D / 128;
+  constexpr int MV8 = (128 * MAXV + 511) / 512;
   const float* xr = p.x + row * p.D;
-  float2 v[MAXV];
-  float s = 0.f;
+  float4 v[MV8][2], sc[MV8][2], sh[MV8][2];
+  bool ok[MV8];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (i < nv) { v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2); s += v[i].x + v[i].y; }
-  float mean = 0.f, rstd;
-  if (p.kind == 0) {
-    mean = wave_sum(s) / p.D;
-    float q = 0.f;
+  for (int i = 0; i < MV8; ++i) {
+    ok[i] = i * 512 + lane * 8 < p.D;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if (i < nv) { const float a = v[i].x - mean, b = v[i].y - mean; q += a * a + b * b; }
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
-  } else {
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if (i < nv) q += v[i].x * v[i].x + v[i].y * v[i].y;
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    for (int k = 0; k < 2; ++k)
+      v[i][k] = ok[i] ? *reinterpret_cast<const float4*>(xr + i * 512 + lane * 8 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
-  bf16_t* yr = p.y + orow * p.D;
-  const int64_t mrow = (row / p.mod_rows) * p.mod_ld;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (i < nv) {
-      const int d = i * 128 + lane * 2;
-      float a = (v[i].x - mean) * rstd, b = (v[i].y - mean) * rstd;
-      if (p.weight) { const float2 w = *reinterpret_cast<const float2*>(p.weight + d); a *= w.x; b *= w.y; }
-      if (p.scale) {
-        float2 sc = *reinterpret_cast<const float2*>(p.scale + mrow + d);
-        float2 sh = *reinterpret_cast<const float2*>(p.shift + mrow + d);
-        if (p.scale_table) {
-          const float2 t0 = *reinterpret_cast<const float2*>(p.scale_table + d);
-          const float2 t1 = *reinterpret_cast<const float2*>(p.shift_table + d);
-          sc.x += t0.x; sc.y += t0.y; sh.x += t1.x; sh.y += t1.y;
-        }
-        a = a * (1.f + sc.x) + sh.x; b = b * (1.f + sc.y) + sh.y;
-      }
-      *reinterpret_cast<uint32_t*>(yr + d) = pack2bf(a, b);
-    }
-}
-
-// D % 256 == 0: 16-byte loads / 8-byte stores (8-byte global accesses run at 0.5-0.7x the 16-byte rate on gfx950)
-__global__ __launch_bounds__(256) void norm_modulate_kernel_v4(NormP p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= p.rows) return;
-  constexpr int MV4 = MAXV / 2;
-  const int nv = p.D / 256;
-  const float* xr = p.x + row * p.D;
-  float4 v[MV4];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MV4; ++i)
-    if (i < nv) { v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
-  float mean = 0.f, rstd;
-  if (p.kind == 0) {
-    mean = wave_sum(s) / p.D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MV4; ++i)
-      if (i < nv) {
-        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        q += (a * a + b * b) + (c * c + d * d);
-      }
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
-  } else {
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MV4; ++i)
-      if (i < nv) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-    rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
-  }
-  const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
-  bf16_t* yr = p.y + orow * p.D;
-  const int64_t mrow = (row / p.mod_rows) * p.mod_ld;
-#pragma unroll
-  for (int i = 0; i < MV4; ++i)
-    if (i < nv) {
-      const int d = i * 256 + lane * 4;
-      float4 o = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
-      if (p.weight) { const float4 w = *reinterpret_cast<const float4*>(p.weight + d); o.x *= w.x; o.y *= w.y; o.z *= w.z; o.w *= w.w; }
-      if (p.scale) {
-        float4 sc = *reinterpret_cast<const float4*>(p.scale + mrow + d);
-        float4 sh = *reinterpret_cast<const float4*>(p.shift + mrow + d);
-        if (p.scale_table) {
-          const float4 t0 = *reinterpret_cast<const float4*>(p.scale_table + d);
-          const float4 t1 = *reinterpret_cast<const float4*>(p.shift_table + d);
-          sc.x += t0.x; sc.y += t0.y; sc.z += t0.z; sc.w += t0.w; sh.x += t1.x; sh.y += t1.y; sh.z += t1.z; sh.w += t1.w;
-        }
-        o.x = o.x * (1.f + sc.x) + sh.x; o.y = o.y * (1.f + sc.y) + sh.y; o.z = o.z * (1.f + sc.z) + sh.z; o.w = o.w * (1.f + sc.w) + sh.w;
-      }
-      uint2 u; u.x = pack2bf(o.x, o.y); u.y = pack2bf(o.z, o.w);
-      *reinterpret_cast<uint2*>(yr + d) = u;
-    }
-}
-
-// D % 512 == 0: every lane owns 8 consecutive features per 512-column chunk: two 16-byte loads, ONE 16-byte bf16 store
-// (8-byte global accesses run at 0.5-0.7x the 16-byte rate on gfx950)
-#ifndef NORM_RPW
-#define NORM_RPW 1          // rows per wavefront; r3 measured 14.0 / 17.2 / 20.4 us at 1 / 2 / 4 rows (12288 x 1024): one row per wave stays
-#endif
-__global__ __launch_bounds__(256) void norm_modulate_kernel_v8(NormP p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NORM_RPW;
-  if (row0 >= p.rows) return;
-  constexpr int MV8 = 2;                 // D <= 1024
-  const int nv = p.D / 512;
-  float4 v[NORM_RPW][MV8][2];
-  float4 sc[NORM_RPW][MV8][2], sh[NORM_RPW][MV8][2];
-#pragma unroll
-  for (int r = 0; r < NORM_RPW; ++r) {
-    const int64_t row = row0 + r < p.rows ? row0 + r : p.rows - 1;
-    const float* xr = p.x + row * p.D;
-#pragma unroll
-    for (int i = 0; i < MV8; ++i)
-      if (i < nv) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) v[r][i][k] = *reinterpret_cast<const float4*>(xr + i * 512 + lane * 8 + 4 * k);
-      }
-  }
-  // r3: the modulation rows do not depend on the statistics - issue their (L2-resident) loads behind the row's own loads instead
+  // the modulation rows do not depend on the statistics - their (L2-resident) loads are issued behind the row's own loads instead
   // of after the two wave reductions, so that their latency is not a second serial segment of the wave's life
   if (p.scale) {
-#pragma unroll
-    for (int r = 0; r < NORM_RPW; ++r) {
-      const int64_t row = row0 + r < p.rows ? row0 + r : p.rows - 1;
-      const int64_t mrow = (row / p.mod_rows) * p.mod_ld;
-#pragma unroll
-      for (int i = 0; i < MV8; ++i)
-        if (i < nv) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int d = i * 512 + lane * 8 + 4 * k;
-            sc[r][i][k] = *reinterpret_cast<const float4*>(p.scale + mrow + d);
-            sh[r][i][k] = *reinterpret_cast<const float4*>(p.shift + mrow + d);
-            if (p.scale_table) {
-              const float4 t0 = *reinterpret_cast<const float4*>(p.scale_table + d);
-              const float4 t1 = *reinterpret_cast<const float4*>(p.shift_table + d);
-              sc[r][i][k].x += t0.x; sc[r][i][k].y += t0.y; sc[r][i][k].z += t0.z; sc[r][i][k].w += t0.w;
-              sh[r][i][k].x += t1.x; sh[r][i][k].y += t1.y; sh[r][i][k].z += t1.z; sh[r][i][k].w += t1.w;
-            }
-          }
-        }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < NORM_RPW; ++r) {
-    const int64_t row = row0 + r;
-    if (row >= p.rows) break;
-    float s = 0.f;
+    const int64_t mrow = (row / p.mod_rows) * p.mod_ld;
 #pragma unroll
     for (int i = 0; i < MV8; ++i)
-      if (i < nv) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) s += (v[r][i][k].x + v[r][i][k].y) + (v[r][i][k].z + v[r][i][k].w);
-      }
-    float mean = 0.f, rstd;
-    if (p.kind == 0) {
-      mean = wave_sum_dpp(s) / p.D;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < MV8; ++i)
-        if (i < nv) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const float a = v[r][i][k].x - mean, b = v[r][i][k].y - mean, c = v[r][i][k].z - mean, d = v[r][i][k].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
-          }
-        }
-      rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
-    } else {
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < MV8; ++i)
-        if (i < nv) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            q += (v[r][i][k].x * v[r][i][k].x + v[r][i][k].y * v[r][i][k].y) + (v[r][i][k].z * v[r][i][k].z + v[r][i][k].w * v[r][i][k].w);
-        }
-      rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
-    }
-    const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
-    bf16_t* yr = p.y + orow * p.D;
-#pragma unroll
-    for (int i = 0; i < MV8; ++i)
-      if (i < nv) {
-        uint32_t pk[4];
+      if (ok[i]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int d = i * 512 + lane * 8 + 4 * k;
-          float4 o = make_float4((v[r][i][k].x - mean) * rstd, (v[r][i][k].y - mean) * rstd, (v[r][i][k].z - mean) * rstd,
-                                 (v[r][i][k].w - mean) * rstd);
-          if (p.weight) { const float4 w = *reinterpret_cast<const float4*>(p.weight + d); o.x *= w.x; o.y *= w.y; o.z *= w.z; o.w *= w.w; }
-          if (p.scale) {
-            o.x = o.x * (1.f + sc[r][i][k].x) + sh[r][i][k].x; o.y = o.y * (1.f + sc[r][i][k].y) + sh[r][i][k].y;
-            o.z = o.z * (1.f + sc[r][i][k].z) + sh[r][i][k].z; o.w = o.w * (1.f + sc[r][i][k].w) + sh[r][i][k].w;
+          sc[i][k] = *reinterpret_cast<const float4*>(p.scale + mrow + d);
+          sh[i][k] = *reinterpret_cast<const float4*>(p.shift + mrow + d);
+          if (p.scale_table) {
+            const float4 t0 = *reinterpret_cast<const float4*>(p.scale_table + d);
+            const float4 t1 = *reinterpret_cast<const float4*>(p.shift_table + d);
+            sc[i][k].x += t0.x; sc[i][k].y += t0.y; sc[i][k].z += t0.z; sc[i][k].w += t0.w;
+            sh[i][k].x += t1.x; sh[i][k].y += t1.y; sh[i][k].z += t1.z; sh[i][k].w += t1.w;
           }
-          pk[2 * k] = pack2bf(o.x, o.y); pk[2 * k + 1] = pack2bf(o.z, o.w);
         }
-        *reinterpret_cast<uint4*>(yr + i * 512 + lane * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
       }
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MV8; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) s += (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w);       // lanes beyond D hold zeros
+  float mean = 0.f, rstd;
+  if (p.kind == 0) {
+    mean = wave_sum_dpp(s) / p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MV8; ++i)
+      if (ok[i]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float a = v[i][k].x - mean, b = v[i][k].y - mean, c = v[i][k].z - mean, d = v[i][k].w - mean;
+          q += (a * a + b * b) + (c * c + d * d);
+        }
+      }
+    rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MV8; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        q += (v[i][k].x * v[i][k].x + v[i][k].y * v[i][k].y) + (v[i][k].z * v[i][k].z + v[i][k].w * v[i][k].w);
+    rstd = rsqrtf(wave_sum_dpp(q) / p.D + p.eps);
+  }
+  const int64_t orow = (row / p.rows_in) * p.rows_out + (row % p.rows_in);
+  bf16_t* yr = p.y + orow * p.D;
+#pragma unroll
+  for (int i = 0; i < MV8; ++i)
+    if (ok[i]) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int d = i * 512 + lane * 8 + 4 * k;
+        float4 o = make_float4((v[i][k].x - mean) * rstd, (v[i][k].y - mean) * rstd, (v[i][k].z - mean) * rstd, (v[i][k].w - mean) * rstd);
+        if (p.weight) { const float4 w = *reinterpret_cast<const float4*>(p.weight + d); o.x *= w.x; o.y *= w.y; o.z *= w.z; o.w *= w.w; }
+        if (p.scale) {
+          o.x = o.x * (1.f + sc[i][k].x) + sh[i][k].x; o.y = o.y * (1.f + sc[i][k].y) + sh[i][k].y;
+          o.z = o.z * (1.f + sc[i][k].z) + sh[i][k].z; o.w = o.w * (1.f + sc[i][k].w) + sh[i][k].w;
+        }
+        pk[2 * k] = pack2bf(o.x, o.y); pk[2 * k + 1] = pack2bf(o.z, o.w);
+      }
+      *reinterpret_cast<uint4*>(yr + i * 512 + lane * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
 }
 
 extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
   if (!a || !a->x || !a->y || a->D % 128 != 0 || a->D > 128 * MAXV || a->rows <= 0) return LN3D_ERR_BAD_ARG;
   if ((a->scale == nullptr) != (a->shift == nullptr)) return LN3D_ERR_BAD_ARG;
+  if (a->scale && (a->mod_ld % 4) != 0) return LN3D_ERR_BAD_ARG;                       // 16-byte modulation quads
   if ((a->scale_table == nullptr) != (a->shift_table == nullptr)) return LN3D_ERR_BAD_ARG;
   NormP p;
   p.x = a->x; p.y = (bf16_t*)a->y; p.rows = a->rows; p.D = a->D; p.kind = a->kind; p.eps = a->eps; p.weight = a->weight;
   p.shift = a->shift; p.scale = a->scale; p.mod_rows = a->mod_rows > 0 ? a->mod_rows : 1; p.mod_ld = a->mod_ld;
   p.shift_table = a->shift_table; p.scale_table = a->scale_table;
   p.rows_in = a->rows_in > 0 ? a->rows_in : (int)a->rows; p.rows_out = a->rows_out > 0 ? a->rows_out : p.rows_in;
-  const bool v4 = (a->D % 256) == 0 && (a->mod_ld % 4) == 0;
-  const bool v8 = v4 && (a->D % 512) == 0 && a->D <= 1024;
-  if (v8) hipLaunchKernelGGL(norm_modulate_kernel_v8, dim3((unsigned)((a->rows + 4 * NORM_RPW - 1) / (4 * NORM_RPW))), dim3(256), 0, (hipStream_t)stream, p);
-  else if (v4) hipLaunchKernelGGL(norm_modulate_kernel_v4, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(norm_modulate_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(norm_modulate_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
   return ln3d_check_launch();
 }
 
@@ -823,7 +698,7 @@ extern "C" const char* ln3d_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int ln3d_abi_version(void) { return 7; }
+extern "C" int ln3d_abi_version(void) { return 8; }
 extern "C" void ln3d_gemm_reload_env(void);
 extern "C" void ln3d_attn_reload_env(void);
 extern "C" void ln3d_reload_env(void) { ln3d_gemm_reload_env(); ln3d_attn_reload_env(); }

@@ -874,16 +874,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     // then writes 16 rows x 64 contiguous bytes of V^T instead of 64 scattered 2-byte elements.
     if constexpr (NI == 2) {
       const int dm = p.heads * p.head_dim;
-      if (p.head_dim == 64 && p.head_dim_pad == 64 && (p.tokens & 31) == 0 && (p.M % p.tokens) == 0 && (p.N % 64) == 0) {
+      // r4: any head size that is a multiple of 8 with heads * head_dim a multiple of 64 (DiT-XL/2: 72 in 128-wide rows) - a wave
+      // row of 64 features then lies inside ONE of q / k / v, and an 8-feature chunk inside one head; the (head, dim) of a lane's
+      // chunk / feature row is computed once per run (it was the 64-wide heads' shift before; XL/2 took the direct path with
+      // 2-byte scattered V^T stores: 142 us for its QKV GEMM).
+      if ((p.head_dim & 7) == 0 && (dm & 63) == 0 && (p.tokens & 31) == 0 && (p.M % p.tokens) == 0 && (p.N % 64) == 0) {
         const int fw0 = f0 + wf * 64;
         const int which = fw0 / dm;                                   // wave-uniform
         const bool tr = fw0 < p.N && ((p.transpose_mask >> which) & 1);
+        const int HD = p.head_dim, DP = p.head_dim_pad;
         __builtin_amdgcn_s_barrier();                                 // ring retired (all waves take this branch)
         if (tr) {
           char* stg = smem + wid * 8192;
-          const int h = (fw0 - which * dm) >> 6;
           bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
           const int fr = lane >> 2, c = lane & 3;
+          int64_t vrow[4];                                            // (head * DP + dim) of the lane's 4 feature rows
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int fr_ = fw0 - which * dm + 16 * it + fr;
+            const int hh_ = fr_ / HD;
+            vrow[it] = (int64_t)hh_ * DP + (fr_ - hh_ * HD);
+          }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int tb = __builtin_amdgcn_readfirstlane(t0 + wt * 32 * NJ + j * 32);
@@ -906,20 +917,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
               uint4 o;
               o.x = pack2bf(v0.x + bv, v0.y + bv); o.y = pack2bf(v0.z + bv, v0.w + bv);
               o.z = pack2bf(v1.x + bv, v1.y + bv); o.w = pack2bf(v1.z + bv, v1.w + bv);
-              *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * 64 + f) * p.tok_pad + t + 8 * c) = o;
+              *reinterpret_cast<uint4*>(dst + ((int64_t)b * p.heads * DP + vrow[it]) * p.tok_pad + t + 8 * c) = o;
             }
           }
         } else if (fw0 < p.N) {
           // q / k: [B, heads, tok_pad, 64] - the wave's 32 tokens x 64 features of one head are 4 KB of CONTIGUOUS memory:
           // stage as usual (row = token), come back with 8 features per lane and store 16 bytes per lane, 1 KB per instruction
           char* stg = smem + wid * 8192;
-          const int h = (fw0 - which * dm) >> 6;
           bf16_t* dst = (bf16_t*)(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
           const int r8 = lane >> 3, c8 = lane & 7;
+          const int fc_ = fw0 - which * dm + 8 * c8;                  // the lane's 8-feature chunk: inside one head
+          const int h = fc_ / HD, d8 = fc_ - h * HD;
           float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
           if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8); b1 = *reinterpret_cast<const float4*>(p.bias + fw0 + 8 * c8 + 4); }
           // fused qk_norm: the 8 lanes c8 = 0..7 of a row hold the 64 features of one (token, head)
-          const float* nw = which == 0 ? p.hn0 : (which == 1 ? p.hn1 : nullptr);
+          const float* nw = (HD == 64 && DP == 64) ? (which == 0 ? p.hn0 : (which == 1 ? p.hn1 : nullptr)) : nullptr;   // the DPP reduction below is the 64-wide heads'
           float4 n0 = make_float4(1.f, 1.f, 1.f, 1.f), n1 = n0;
           if (nw) { n0 = *reinterpret_cast<const float4*>(nw + 8 * c8); n1 = *reinterpret_cast<const float4*>(nw + 8 * c8 + 4); }
 #pragma unroll
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
               uint4 o;
               o.x = pack2bf(v0.x, v0.y); o.y = pack2bf(v0.z, v0.w);
               o.z = pack2bf(v1.x, v1.y); o.w = pack2bf(v1.z, v1.w);
-              *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * p.tok_pad + t + row) * 64 + 8 * c8) = o;
+              *reinterpret_cast<uint4*>(dst + (((int64_t)b * p.heads + h) * p.tok_pad + t + row) * DP + d8) = o;
             }
           }
         }
@@ -1097,7 +1109,12 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
   p.rb = a->epilogue == LN3D_EPI_GATE_RES ? a->res_bias : nullptr; p.rb_ld = a->res_bias_ld;
   hipStream_t s = (hipStream_t)stream;
-  const int cfg = pick_cfg(a->M, a->N, a->epilogue == LN3D_EPI_HEADS && a->head_dim == 64 && a->head_dim_pad <= 64);
+  // head split: the tiles whose wave row is 64 features (NI = 2) have the staged, head-aware epilogue (any head size that is a
+  // multiple of 8 with heads * head_dim a multiple of 64)
+  const bool head_staged = a->epilogue == LN3D_EPI_HEADS && a->head_dim > 0 && (a->head_dim & 7) == 0 && a->heads > 0 &&
+                           ((a->heads * a->head_dim) & 63) == 0 && a->tokens > 0 && (a->tokens & 31) == 0 && (a->M % a->tokens) == 0 &&
+                           (a->N % 64) == 0;
+  const int cfg = pick_cfg(a->M, a->N, head_staged);
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);
     case LN3D_EPI_BF16: return run_cfg<LN3D_EPI_BF16>(p, s, cfg);

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .. import ops, _cache
 from .dit_models_xformers import (CaptionEmbedder, ImageCondDiTBlock, ImageCondDiTBlockPixelArtRMSNorm, RMSNormP, T2IFinalLayer, bf16, f32,
-                                  self_attention_hip, pad_head_columns, attn_head_pad)
+                                  self_attention_hip, pad_head_columns, attn_head_pad, attn_out_dim)
 from .dit_trilatent import DiT, DiT_TriLatent
 
 
@@ -249,10 +249,12 @@ class DiT_I23D_PixelArt(DiT_TriLatent):
                 sa_k, sa_vt, npad, Dp = akv
                 ops.norm_modulate(xt, hb, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N, mod_ld=ld)
                 qs = ws.get('sa_q', (Bn, H, npad, Dp), torch.bfloat16, zero=True)
-                ao = ws.get('sa_o', (M, H * Dp), torch.bfloat16)
+                Do = attn_out_dim(D // H)
+                ao = ws.get('sa_o', (M, H * Do), torch.bfloat16)
                 ops.gemm(hb, q['qkv_w'], q['qkv_b'], ops.EPI_HEADS, qs, sa_k[i], sa_vt[i], M=M, tokens=N, tok_pad=npad, heads=H,
                          head_dim=D // H, transpose_mask=0b100, head_dim_pad=Dp, head_norm0=q['qn'], head_norm1=q['kn'])
-                ops.attention(qs, sa_k[i], sa_vt[i], ao, Bn, H, N, npad, NA, npad, Dp, scale=(D // H) ** -0.5)
+                ops.attention(qs, sa_k[i], sa_vt[i], ao, Bn, H, N, npad, NA, npad, Dp, scale=(D // H) ** -0.5,
+                              dh_true=(D // H) if Do != Dp else 0)
             else:
                 ops.norm_modulate(xt, ha, M, D, kind=nk, eps=neps, weight=q['n1'], shift=mi[:, 0:], scale=mi[:, D:], mod_rows=N,
                                   mod_ld=ld, rows_in=N, rows_out=NA)

@@ -228,9 +228,15 @@ def attn_head_pad(Dh):
     return Dh if Dh in (64, 128) else 128
 
 
+def attn_out_dim(Dh):
+    """Width of one head in the attention OUTPUT: the kernel writes compact heads for the padded sizes it knows (72 -> 72, ABI 8),
+    the stored width otherwise."""
+    return Dh if Dh in (64, 72, 128) else attn_head_pad(Dh)
+
+
 def pad_head_columns(w, H, Dh):
-    """proj weight [D_out, H*Dh] -> [D_out, H*Dh_pad] with zero columns, matching the padded attention output."""
-    Dp = attn_head_pad(Dh)
+    """proj weight [D_out, H*Dh] -> [D_out, H*attn_out_dim] with zero columns, matching the attention output's head width."""
+    Dp = attn_out_dim(Dh)
     if Dp == Dh:
         return w
     out = w.new_zeros(w.shape[0], H, Dp)
@@ -239,9 +245,10 @@ def pad_head_columns(w, H, Dh):
 
 
 def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=None, nq=None):
-    """h [B*N, D] bf16 -> attention output bf16 [B*nq, H*Dh_pad] (nq <= N query rows kept).  For head sizes other than
-    64/128 the QKV epilogue writes into 128-wide zero-initialised heads (exact: the extra dims contribute 0 to q.k and
-    produce 0 output columns, which meet zero columns of the padded proj weight)."""
+    """h [B*N, D] bf16 -> attention output bf16 [B*nq, H*attn_out_dim] (nq <= N query rows kept).  For head sizes other than
+    64/128 the QKV epilogue writes into 128-wide zero-initialised heads (exact: the extra dims contribute 0 to q.k); the kernel
+    skips the padding for the sizes it knows (DiT-XL/2's 72: compact output, unpadded proj weight), otherwise it produces 0 output
+    columns, which meet zero columns of the padded proj weight."""
     Dh = D // H
     Dp = attn_head_pad(Dh)
     nq = N if nq is None else nq
@@ -249,14 +256,15 @@ def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=No
     q = ws.get(tag + 'q', (B, H, npad, Dp), torch.bfloat16, zero=True)
     k = ws.get(tag + 'k', (B, H, npad, Dp), torch.bfloat16, zero=True)
     vt = ws.get(tag + 'vt', (B, H, Dp, npad), torch.bfloat16, zero=True)
-    o = ws.get(tag + 'o', (B * nq, H * Dp), torch.bfloat16)
+    Do = attn_out_dim(Dh)
+    o = ws.get(tag + 'o', (B * nq, H * Do), torch.bfloat16)
     fused = qn is not None and ops.heads_norm_fusable(B * N, qkv_w.shape[0], N, Dh, Dp)
     ops.gemm(h_bf16, qkv_w, qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
              transpose_mask=0b100, head_dim_pad=Dp, head_norm0=qn if fused else None, head_norm1=kn if fused else None)
     if qn is not None and not fused:
         ops.rmsnorm_heads(q, qn, B * H * npad, Dp, true_dim=Dh)      # qn / kn: [Dp] (zero beyond Dh when padded)
         ops.rmsnorm_heads(k, kn, B * H * npad, Dp, true_dim=Dh)
-    ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dp, scale=Dh ** -0.5)
+    ops.attention(q, k, vt, o, B, H, nq, npad, N, npad, Dp, scale=Dh ** -0.5, dh_true=Dh if Do != Dp else 0)
     return o
 
 

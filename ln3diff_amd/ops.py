@@ -63,12 +63,14 @@ def heads_norm_fusable(M, N, tokens, head_dim, head_dim_pad=0):
     return bool(L.lib().ln3d_gemm_heads_norm_fusable(int(M), int(N), int(tokens), int(head_dim), int(head_dim_pad)))
 
 
-def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causal=False):
+def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causal=False, dh_true=0):
+    """dh_true: true head size when q / k / vt rows are zero-padded to Dh; the output is then compact [B, Nq, H * dh_true]."""
     _chk_dev(q, k, vt, out)
     a = L.AttnArgs()
     a.Q, a.K, a.Vt, a.O = _p(q), _p(k), _p(vt), _p(out)
     a.B, a.H, a.Nq, a.Nq_pad, a.Nk, a.Nk_pad, a.Dh = B, H, Nq, Nq_pad, Nk, Nk_pad, Dh
-    a.ldo = H * Dh
+    a.Dh_true = int(dh_true)
+    a.ldo = H * (dh_true if dh_true and dh_true != Dh else Dh)
     a.scale = float(scale if scale is not None else Dh ** -0.5)
     a.causal = int(bool(causal))
     L.check(L.lib().ln3d_attention_bf16(C.byref(a), _stream()), "attention")

@@ -60,7 +60,7 @@ def test_every_entry_point_rejects_missing_buffers(hip_lib):
 
 
 def test_host_queries(hip_lib):
-    assert hip_lib.ln3d_abi_version() == 7
+    assert hip_lib.ln3d_abi_version() == 8
     # the fused qk-norm epilogue needs head-aligned tiles: 64-wide heads yes, 72-in-128 padded heads no
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3072, 768, 64, 64) == 1
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3 * 16 * 128, 768, 72, 128) == 0

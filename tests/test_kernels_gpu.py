@@ -148,6 +148,30 @@ def test_gemm_heads_split(ops):
     assert float(q[:, :, T:].abs().max()) == 0 and float(vt_nat[:, :, :, T:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,T,H,K", [(2, 768, 16, 1152), (3, 96, 8, 128)])
+def test_gemm_heads_split_head_size_72_padded(ops, B, T, H, K):
+    """DiT-XL/2 head split: 72-wide heads written into zero-initialised 128-wide rows (q, k) / 128 rows (V^T).  r4: the staged,
+    head-aware epilogue serves it (8-feature chunks lie inside one head) instead of the scattered direct stores; every tile
+    configuration must agree with fp32 torch and leave the padding untouched."""
+    dev, Dh, Dp = 'cuda', 72, 128
+    g = torch.Generator().manual_seed(B * 10 + T)
+    x = torch.randn(B * T, K, generator=g).to(dev)
+    w = (torch.randn(3 * H * Dh, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(3 * H * Dh, generator=g).to(dev)
+    xb, wb = _bf(x), _bf(w)
+    ref = (xb.float() @ wb.float().t() + b).reshape(B, T, 3, H, Dh)
+    q = torch.zeros(B, H, T, Dp, device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, Dp, T, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, b, ops.EPI_HEADS, q, k, vt, M=B * T, tokens=T, tok_pad=T, heads=H, head_dim=Dh, transpose_mask=0b100, head_dim_pad=Dp)
+    assert rel_l2(q[..., :Dh].float(), ref[:, :, 0].permute(0, 2, 1, 3)) < 4e-3
+    assert rel_l2(k[..., :Dh].float(), ref[:, :, 1].permute(0, 2, 1, 3)) < 4e-3
+    vt_nat = torch.zeros_like(vt)
+    vt_nat[..., ops.vt_key_order(T, dev)] = vt
+    assert rel_l2(vt_nat[:, :, :Dh].float(), ref[:, :, 2].permute(0, 2, 3, 1)) < 4e-3
+    assert float(q[..., Dh:].abs().max()) == 0 and float(k[..., Dh:].abs().max()) == 0 and float(vt[:, :, Dh:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("B,T,H,K", [(4, 768, 16, 1024), (2, 1024, 4, 256), (3, 800, 2, 128)])
 def test_gemm_heads_split_with_fused_qk_norm(ops, B, T, H, K):
     """HEADS epilogue with head_norm0 / head_norm1: q, k = RMSNorm_64(x W^T + b) * w per (token, head), one rounding to bf16;
@@ -223,6 +247,52 @@ def test_attention(ops, B, H, Nq, Nk, Dh):
     ref = ref.permute(0, 2, 1, 3).reshape(B, Nq, H * Dh)
     e = rel_l2(out.float(), ref)
     assert e < 1e-2, e
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 16, 768, 768), (1, 3, 300, 1024), (16, 16, 768, 768)])
+def test_attention_head_size_72_in_padded_rows(hip_lib, B, H, Nq, Nk):
+    """r4 (ABI 8): DiT-XL/2 heads (72) stored zero-padded to 128.  The kernel contracts over 80 dims, produces 96 output rows and
+    writes COMPACT [B, Nq, H * 72] heads.  Against fp32 torch on the same bf16 operands, against the padded-128 run of the same
+    kernel family (same values, other layout), spiked keys force the rescale branch; the largest case prints both timings."""
+    from ln3diff_amd import ops
+    dev, Dh, Dp = 'cuda', 72, 128
+    g = torch.Generator().manual_seed(Nq + Nk + B)
+    nqp, nkp = (Nq + 63) // 64 * 64, (Nk + 63) // 64 * 64
+    q = torch.zeros(B, H, nqp, Dp); k = torch.zeros(B, H, nkp, Dp); v = torch.zeros(B, H, nkp, Dp)
+    q[:, :, :Nq, :Dh] = torch.randn(B, H, Nq, Dh, generator=g) * 1.5
+    k[:, :, :Nk, :Dh] = torch.randn(B, H, Nk, Dh, generator=g) * 1.5
+    v[:, :, :Nk, :Dh] = torch.randn(B, H, Nk, Dh, generator=g) + torch.arange(Dh) / Dh
+    k[:, :, Nk - 5] = q[:, :, 3] * 4.0
+    qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
+    vt = vb.transpose(-1, -2)[..., ops.vt_key_order(nkp, dev)].contiguous()
+    out = torch.full((B, Nq, H * Dh), float('nan'), device=dev, dtype=torch.bfloat16)
+    ops.attention(qb, kb, vt, out, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5, dh_true=Dh)
+    ref = _attn_ref(qb[:, :, :Nq, :Dh], kb[:, :, :Nk, :Dh], vb[:, :, :Nk, :Dh], Dh ** -0.5).permute(0, 2, 1, 3).reshape(B, Nq, H * Dh)
+    assert torch.isfinite(out.float()).all()
+    e = rel_l2(out.float(), ref)
+    assert e < 1e-2, e
+    full = torch.empty(B, Nq, H * Dp, device=dev, dtype=torch.bfloat16)
+    ops.attention(qb, kb, vt, full, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5)
+    full = full.reshape(B, Nq, H, Dp)
+    assert float(full[..., Dh:].abs().max()) == 0.0
+    assert rel_l2(out.float(), full[..., :Dh].reshape(B, Nq, H * Dh).float()) < 2e-3
+    out2 = torch.empty_like(out)
+    ops.attention(qb, kb, vt, out2, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5, dh_true=Dh)
+    assert torch.equal(out, out2)                                        # run-to-run determinism
+    if B * H >= 256:
+        def t(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 20 * 1e3
+        t72 = t(lambda: ops.attention(qb, kb, vt, out, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5, dh_true=Dh))
+        t128 = t(lambda: ops.attention(qb, kb, vt, full, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5))
+        print(f"XL/2 self-attention {B}x{H} heads {Nq}x{Nk}: Dh_true 72 {t72:.1f} us, padded 128 {t128:.1f} us")
+        assert t72 < t128
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 256, 256), (1, 3, 512, 512), (5, 8, 768, 768), (19, 16, 768, 1024), (1, 2, 1280, 1280),
