@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--dec-arch", default="DiT2-L/2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--ode-method", default="euler", choices=["euler", "heun", "dopri5"],
+                    help="i23d workload: euler = configs[2] (50 fixed steps); dopri5 = the released sampler's default (torchdiffeq "
+                         "semantics, atol 1e-6, rtol 1e-3: the number of network evaluations is decided by the solver and reported)")
     ap.add_argument("--dist", action="store_true",
                     help="go through torch.distributed.run + an RCCL process group even with --gpus 1 (the N-GPU code path on one GPU)")
     args = ap.parse_args()
@@ -398,7 +401,7 @@ def main():
     lo, hi = parallel.shard_range(Bt, rank, world)
     cams = orbit_cameras(args.views).to(dev)
     if i23d:
-        eng = FlowMatchingEngine(dit, dec, sampling_method='euler')             # configs[2]: 50 fixed steps
+        eng = FlowMatchingEngine(dit, dec, sampling_method=args.ode_method)     # configs[2]: euler, 50 fixed steps
         c_all = {'crossattn': torch.randn(Bt, 256, 2048, device=dev, generator=g), 'vector': torch.randn(Bt, 768, device=dev, generator=g)}
         c_all['crossattn'][0] = synth_input('ca', (1, 256, 2048), gseed)[0].to(dev)
         c_all['vector'][0] = synth_input('v', (1, 768), gseed)[0].to(dev)
@@ -451,16 +454,18 @@ def main():
 
     if rank == 0:
         if i23d:
-            wl = ("BASELINE configs[2]: %s image-cond I23D, flow-matching ODE euler num_steps %d (= %d network evaluations per "
-                  "sample, each on the CFG-doubled batch), CFG 4.0, batch %d per GPU, VAE decode %s + conv decoder, %d views @ %d^2 "
-                  "(64+64 samples/ray)" % (args.arch, args.sample_steps, args.sample_steps - 1, B, args.dec_arch, args.views, args.res))
+            evals = ("= %d network evaluations per sample" % (args.sample_steps - 1) if args.ode_method == "euler" else
+                     "= %d per sample" % (2 * (args.sample_steps - 1)) if args.ode_method == "heun" else "network evaluations decided by the solver: see 'ode'")
+            wl = ("BASELINE configs[2]: %s image-cond I23D, flow-matching ODE %s num_steps %d (%s, each on the CFG-doubled batch), CFG 4.0, "
+                  "batch %d per GPU, VAE decode %s + conv decoder, %d views @ %d^2 (64+64 samples/ray)"
+                  % (args.arch, args.ode_method, args.sample_steps, evals, B, args.dec_arch, args.views, args.res))
             metric = "3D samples/sec (50-step flow-matching DiT-PixArt-L/2 + triplane decode + 256^2 render)"
         else:
             wl = ("BASELINE configs[1]: %s text-cond T23D, EulerEDM/LegacyDDPM-sigma %d steps, CFG 6.5 (network batch 2B), batch %d "
                   "per GPU, VAE decode %s + conv decoder, %d views @ %d^2 (64+64 samples/ray)"
                   % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res))
             metric = "3D samples/sec (250-step DiT-L/2 + 256^2 triplane render)"
-        ref_cfg = dict(arch="DiT-PixArt-L/2", sample_steps=50, batch=32, views=24, res=256) if i23d else \
+        ref_cfg = dict(arch="DiT-PixArt-L/2", sample_steps=50, batch=32, views=24, res=256, ode_method="euler") if i23d else \
             dict(arch="DiT-L/2", sample_steps=250, batch=8, views=40, res=256)
         dev_from = {k: getattr(args, k) for k, v in ref_cfg.items() if getattr(args, k) != v}
         if dev_from:           # a reduced / altered run must not pass for the headline configuration
@@ -474,8 +479,14 @@ def main():
                        "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
             "finite": ok,
             "ranks_seen": seen, "collectives": parallel.collective_info(), "bcast_ms": round(bcast_ms, 2),
-            "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps),
+            "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps if (not i23d or args.ode_method == "euler") else -1),
         }
+        if i23d:
+            rec["ode"] = {"method": args.ode_method}
+            st = getattr(eng, "last_ode_stats", None)
+            if st:              # adaptive solver (rank 0's shard of the LAST timed step): the solver, not --sample-steps, decides the work
+                rec["ode"].update({"nfe": st["nfe"], "steps_attempted": st["steps"], "steps_accepted": st["accepted"], "t_end": round(st["t_end"], 6),
+                                   "atol": 1e-6, "rtol": 1e-3, "output_grid": "linspace(0, 1, %d)[-1] by 4th-order dense output" % args.sample_steps})
         if not args.no_probes:
             D = dit.embed_dim
             ev = dit._fc1_probe['events'] if getattr(dit, '_fc1_probe', None) else []

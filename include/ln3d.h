@@ -126,9 +126,13 @@ int ln3d_layernorm_f32(const float* x, const float* w, const float* b, float* y,
 
 /* ---------------------------------------------------------------- image conditioner helpers (open_clip ViT-L/14 visual tower,
  * DINOv2 ViT-L/14-reg: sgm/modules/encoders/modules.py:578-869)
- * patchify: out bf16 [B*(S/p)^2, Kpad], column c*p*p + i*p + j = img[b, c, gy*p+i, gx*p+j], columns >= 3*p*p zero
+ * patchify: out bf16 [B*(S/p)^2, Kpad], column c*p*p + i*p + j = img[b, c, gy*p+i, gx*p+j], columns >= C*p*p zero
  * assemble: x f32 [B, 1+R+L, D]: cls + pos[0] ; R register tokens ; patch[b, n] + pos[1+n] */
-int ln3d_vit_patchify(const float* img, void* out_bf16, int B, int S, int p, int Kpad, void* stream);
+int ln3d_vit_patchify(const float* img, void* out_bf16, int B, int S, int p, int Kpad, int C, void* stream);   /* ABI 8: C input channels (3; 9 = RGB + Pluecker rays) */
+/* Pluecker ray maps of V posed views for the multi-view conditioner (FrozenDinov2ImageEmbedderMVPlucker.get_plucker_ray,
+ * sgm/modules/encoders/modules.py:958-1005): c f32 [V, 25] = camera-to-world 4x4 (row-major) + normalised intrinsics 3x3;
+ * out f32 [V, 6, S, S] = (origin x direction, direction) per pixel centre of an S x S grid. */
+int ln3d_plucker_rays(const float* c, float* out, int V, int S, void* stream);
 int ln3d_vit_assemble(const float* patch, const float* cls, const float* reg, const float* pos, float* x, int B, int L, int R, int D,
                       void* stream);
 /* kornia.geometry.transform.resize(x, (S, S), 'bicubic', align_corners=True, antialias) -> (x + 1) / 2 -> (x - mean) / std

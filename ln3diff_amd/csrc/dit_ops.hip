@@ -170,9 +170,9 @@ extern "C" int ln3d_layernorm_f32(const float* x, const float* w, const float* b
 // ------------------------------------------------------------------ image conditioner helpers (ViT towers)
 // out[(b*G + gy)*G + gx, c*p*p + i*p + j] = bf16(img[b, c, gy*p + i, gx*p + j]), columns >= 3*p*p zero (K padded to a
 // multiple of 64 for the GEMM): the patch-embedding convolution (kernel = stride = p) becomes one GEMM
-__global__ void vit_patchify_kernel(const float* img, bf16_t* out, int B, int S, int p, int Kpad) {
+__global__ void vit_patchify_kernel(const float* img, bf16_t* out, int B, int S, int p, int Kpad, int C) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int G = S / p, KK = 3 * p * p;
+  const int G = S / p, KK = C * p * p;
   const int64_t total = (int64_t)B * G * G * Kpad;
   if (i >= total) return;
   const int k = (int)(i % Kpad);
@@ -181,14 +181,40 @@ __global__ void vit_patchify_kernel(const float* img, bf16_t* out, int B, int S,
   if (k < KK) {
     const int c = k / (p * p), ij = k - c * p * p, ii = ij / p, jj = ij - ii * p;
     const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((int64_t)G * G));
-    v = img[(((int64_t)b * 3 + c) * S + gy * p + ii) * S + gx * p + jj];
+    v = img[(((int64_t)b * C + c) * S + gy * p + ii) * S + gx * p + jj];
   }
   out[i] = f2bf(v);
 }
-extern "C" int ln3d_vit_patchify(const float* img, void* out, int B, int S, int p, int Kpad, void* stream) {
-  if (!img || !out || B <= 0 || S <= 0 || p <= 0 || S % p || Kpad < 3 * p * p) return LN3D_ERR_BAD_ARG;
+extern "C" int ln3d_vit_patchify(const float* img, void* out, int B, int S, int p, int Kpad, int C, void* stream) {
+  if (!img || !out || B <= 0 || S <= 0 || p <= 0 || S % p || C <= 0 || Kpad < C * p * p) return LN3D_ERR_BAD_ARG;
   const int64_t total = (int64_t)B * (S / p) * (S / p) * Kpad;
-  hipLaunchKernelGGL(vit_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, S, p, Kpad);
+  hipLaunchKernelGGL(vit_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, S, p, Kpad, C);
+  return ln3d_check_launch();
+}
+// Pluecker ray maps of posed views (multi-view conditioner, sgm/modules/encoders/modules.py:958-1005 gen_rays / get_plucker_ray):
+// c[v] = 16 floats camera-to-world (row-major 4x4) + 9 floats normalised intrinsics (fx, 0, cx, 0, fy, cy, 0, 0, 1);
+// pixel (y, x) of an S x S grid looks along normalize(((x + .5) / S - cx) / fx, ((y + .5) / S - cy) / fy, 1) rotated by c2w[:3,:3];
+// out[v, 0:3] = origin x direction, out[v, 3:6] = direction   (fp32 [V, 6, S, S])
+__global__ void plucker_rays_kernel(const float* c, float* out, int V, int S) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)V * S * S) return;
+  const int x = (int)(i % S), y = (int)((i / S) % S), v = (int)(i / ((int64_t)S * S));
+  const float* cv = c + (int64_t)v * 25;
+  const float fx = cv[16], cx = cv[18], fy = cv[20], cy = cv[21];
+  float dx = (((float)x + 0.5f) / (float)S - cx) / fx, dy = (((float)y + 0.5f) / (float)S - cy) / fy, dz = 1.0f;
+  const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+  dx /= n; dy /= n; dz /= n;
+  const float wx = cv[0] * dx + cv[1] * dy + cv[2] * dz, wy = cv[4] * dx + cv[5] * dy + cv[6] * dz, wz = cv[8] * dx + cv[9] * dy + cv[10] * dz;
+  const float ox = cv[3], oy = cv[7], oz = cv[11];
+  float* o = out + (int64_t)v * 6 * S * S + (int64_t)y * S + x;
+  const int64_t pl = (int64_t)S * S;
+  o[0] = oy * wz - oz * wy; o[pl] = oz * wx - ox * wz; o[2 * pl] = ox * wy - oy * wx;
+  o[3 * pl] = wx; o[4 * pl] = wy; o[5 * pl] = wz;
+}
+extern "C" int ln3d_plucker_rays(const float* c, float* out, int V, int S, void* stream) {
+  if (!c || !out || V <= 0 || S <= 0) return LN3D_ERR_BAD_ARG;
+  const int64_t total = (int64_t)V * S * S;
+  hipLaunchKernelGGL(plucker_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c, out, V, S);
   return ln3d_check_launch();
 }
 // x[b, 0] = cls + pos[0]; x[b, 1..R] = reg; x[b, 1+R+n] = patch[b, n] + pos[1+n]   (f32, T = 1 + R + L tokens)

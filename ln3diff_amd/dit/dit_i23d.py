@@ -661,6 +661,7 @@ def DiT_B_1(**kwargs):
     return DiT_I23D(depth=12, hidden_size=768, patch_size=1, num_heads=12, **kwargs)
 
 
+MV_NOCLIP_ARCHS = {'DiT-PixArt-MV-L/2'}        # registry keys built on DiT_I23D_PixelArt_MVCond_noClip (no CLIP tokens in the context)
 DiT_models = {'DiT-XL/2': DiT_XL_2, 'DiT-L/2': DiT_L_2, 'DiT-B/2': DiT_B_2, 'DiT-B/1': DiT_B_1,
               'DiT-PixArt-L/2': DiT_L_Pixelart_2, 'DiT-PixArt-B/2': DiT_B_Pixelart_2,
               # reference registry (dit_i23d.py:686-696): 'MV-L/2' is the no-CLIP class, 'MV-B/2' the CLIP+DINO one

@@ -75,7 +75,7 @@ def create_argparser(objaverse=True):
         mesh_grid=192, mesh_thres=10.0, logdir='./logs/sample', resume_checkpoint='', ddpm_model_path='', rec_model_path='',
         cond_path='', pose_path='', seed=41 if objaverse else 0, context_dim=768, learn_sigma=False, denoise_in_channels=4,
         diffusion_input_size=32, roll_out=True, prompt=None, cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
-        mv_input=False, num_mv_views=4, clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
+        mv_input=False, num_mv_views=4, mv_dino_arch='vitl', clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
         overwrite_diff_inp_size='', create_controlnet=False)
     d.update(_IGNORED_DEFAULTS)
     d.update({k: v[0] for k, v in _CHECKED.items()})
@@ -154,7 +154,10 @@ def build_models(args, dev, rank):
     common = dict(input_size=args.diffusion_input_size, num_classes=0, learn_sigma=args.learn_sigma,
                   in_channels=args.denoise_in_channels, roll_out=args.roll_out)
     if args.i23d:
-        dit = I23D[args.dit_model_arch](context_dim=1024, pooling_ctx_dim=768, **common)
+        # multi-view denoisers cross-attend to the raw multi-view DINO tokens: their context width is the conditioner tower's
+        # (--mv_dino_arch: vitl 1024, the released mv23d-plucker configs' vitb 768)
+        ctx_dim = _MV_DINO_WIDTH[args.mv_dino_arch] if args.mv_input else 1024
+        dit = I23D[args.dit_model_arch](context_dim=ctx_dim, pooling_ctx_dim=768, **common)
     else:
         dit = T23D[args.dit_model_arch](context_dim=args.context_dim, vit_blk=TextCondDiTBlock, **common)
     vit = DiT2_models[args.arch_dit_decoder](input_size=16, num_classes=0, learn_sigma=False, in_channels=dit.embed_dim,
@@ -186,6 +189,9 @@ def build_models(args, dev, rank):
     return dit, AE(None, dec, args.image_size), dec, got
 
 
+_MV_DINO_WIDTH = {'vits': 384, 'vitb': 768, 'vitl': 1024}
+
+
 def load_conditioning(args, dev, objaverse=True):
     """({'crossattn', 'vector'[, 'concat']} for P prompts, source).  Sources, in order: --cond_path tensors; the HIP conditioners on
     --prompt (CLIP-L text tower, T23D) / --image_path (OpenCLIP ViT-L/14 + DINOv2 ViT-L/14-reg, I23D) when their checkpoints are
@@ -202,8 +208,37 @@ def load_conditioning(args, dev, objaverse=True):
         if not args.i23d:
             raise SystemExit("--image_path conditions the I23D models: pass --i23d true (and --trainer_name flow_matching)")
         if args.mv_input:
-            raise SystemExit("--image_path with a multi-view (MV) denoiser: the multi-view conditioner (4 posed views -> 'concat' tokens) "
-                             "is not wired into this entry point; pass the conditioning tensors with --cond_path")
+            # multi-view denoisers (DiT-PixArt-MV-*): --image_path is an .npz with 'img' [T, 3, H, W] (or [T, H, W, 3] uint8) and 'c'
+            # [T, 25] (camera-to-world 4x4 + normalised intrinsics 3x3 per view); the first --num_mv_views views condition the sample
+            # through FrozenDinov2ImageEmbedderMVPlucker (released mv23d-plucker configs), the first view through OpenCLIP for the
+            # non-noClip denoisers
+            if not args.image_path.endswith('.npz'):
+                raise SystemExit("--image_path with a multi-view (MV) denoiser expects an .npz holding 'img' [T, 3, H, W] and 'c' [T, 25]")
+            from .dit.dit_i23d import MV_NOCLIP_ARCHS
+            noclip = args.dit_model_arch in MV_NOCLIP_ARCHS
+            if not args.dino_checkpoint or (not noclip and not args.clip_checkpoint):
+                raise SystemExit("--image_path with an MV denoiser needs --dino_checkpoint (embedder_FrozenDinov2ImageEmbedderMVPlucker*.pt)"
+                                 + ("" if noclip else " and --clip_checkpoint (open_clip ViT-L/14 visual tower)") +
+                                 ": without them the views cannot be encoded (refusing to sample from synthetic conditioning)")
+            from .sgm.image_encoders import FrozenOpenCLIPImageEmbedder, FrozenDinov2ImageEmbedderMVPlucker, MV23DConditioner
+            raw = np.load(args.image_path)
+            img = torch.as_tensor(raw['img'])
+            if img.dtype == torch.uint8:
+                img = img.float() / 127.5 - 1.0
+            if img.ndim == 4 and img.shape[-1] == 3:
+                img = img.permute(0, 3, 1, 2)
+            cam = torch.as_tensor(raw['c']).float().reshape(img.shape[0], 25)
+            if img.shape[0] < args.num_mv_views:
+                raise SystemExit(f"--image_path holds {img.shape[0]} views, the denoiser is conditioned on --num_mv_views {args.num_mv_views}")
+            dino = FrozenDinov2ImageEmbedderMVPlucker(arch=args.mv_dino_arch, n_cond_frames=args.num_mv_views, device=str(dev))
+            load_checkpoint(args.dino_checkpoint, conditioner=dino)
+            clip = None
+            if not noclip:
+                clip = FrozenOpenCLIPImageEmbedder(device=str(dev), output_tokens=True)
+                load_checkpoint(args.clip_checkpoint, conditioner=clip.model)
+                clip = clip.to(dev)
+            c = MV23DConditioner(dino.to(dev), clip)({'img': img.float()[None].to(dev), 'c': cam[None].to(dev)})
+            return {k: v.float().cpu() for k, v in c.items()}, f'MV23DConditioner({args.image_path}, {args.num_mv_views} views)'
         if not (args.clip_checkpoint and args.dino_checkpoint):
             raise SystemExit("--image_path needs --clip_checkpoint (open_clip ViT-L/14 visual tower) and --dino_checkpoint (DINOv2 "
                              "ViT-L/14-reg): without them the image cannot be encoded (refusing to sample from synthetic conditioning)")
@@ -231,7 +266,7 @@ def load_conditioning(args, dev, objaverse=True):
         vdim = 768 if 'PixArt' in args.dit_model_arch else 1024
         c = {'crossattn': synth_input('prompt', (1, 256, 1024 if mv else 2048), args.seed), 'vector': synth_input('vec', (1, vdim), args.seed)}
         if mv:
-            c['concat'] = synth_input('mv', (1, args.num_mv_views, 256, 1024), args.seed)
+            c['concat'] = synth_input('mv', (1, args.num_mv_views, 256, _MV_DINO_WIDTH[args.mv_dino_arch]), args.seed)
         return c, 'synthetic'
     return ({'crossattn': synth_input('prompt', (1, 77, args.context_dim), args.seed), 'vector': synth_input('vec', (1, 768), args.seed)},
             'synthetic')
@@ -303,7 +338,7 @@ def run(args, objaverse=None):
         meta = dict(vars(args), conditioning=cond_src, weights={k: (v or 'synthetic') for k, v in weights_from.items()})
         with open(os.path.join(args.logdir, 'args.json'), 'w') as f:
             json.dump(meta, f, indent=2)
-    P = cond_all['crossattn'].shape[0]
+    P = next(iter(cond_all.values())).shape[0]                                             # the noClip multi-view denoisers take 'concat' only
     cond_all = {k: v.repeat_interleave(args.num_samples, 0) for k, v in cond_all.items()}     # one condition x num_samples
     Bt = P * args.num_samples
     S = int(args.overwrite_diff_inp_size) if args.overwrite_diff_inp_size else args.diffusion_input_size

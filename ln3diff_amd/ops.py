@@ -255,8 +255,17 @@ def image_preprocess(x, S, antialias, mean, std):
     return out
 
 
-def vit_patchify(img, out, B, S, p, Kpad):
-    L.check(L.lib().ln3d_vit_patchify(_p(img), _p(out), B, S, p, Kpad, _stream()), "vit_patchify")
+def vit_patchify(img, out, B, S, p, Kpad, C=3):
+    L.check(L.lib().ln3d_vit_patchify(_p(img), _p(out), B, S, p, Kpad, C, _stream()), "vit_patchify")
+
+
+def plucker_rays(c, S):
+    """c f32 [V, 25] (c2w 4x4 + intrinsics 3x3) -> Pluecker maps f32 [V, 6, S, S] (o x d, d)."""
+    _chk_dev(c)
+    V = c.shape[0]
+    out = torch.empty(V, 6, S, S, device=c.device, dtype=torch.float32)
+    L.check(L.lib().ln3d_plucker_rays(_p(c.contiguous().float()), _p(out), V, S, _stream()), "plucker_rays")
+    return out
 
 
 def vit_assemble(patch, cls, reg, pos, x, B, Lp, R, D):

@@ -201,7 +201,7 @@ class FlowMatchingEngine:
     def sample(self, cond, uc=None, batch_size=16, shape=None, use_cfg=True, cfg_scale=4.0, num_steps=250, seed=42, zs=None, **kwargs):
         assert use_cfg
         uc = _zero_uc(cond) if uc is None else uc
-        dev = cond['crossattn'].device
+        dev = next(iter(cond.values())).device
         shape = shape or (3 * self.ddpm_model.in_channels if self.ddpm_model.roll_out else self.ddpm_model.in_channels, 32, 32)
         if zs is None:
             torch.manual_seed(seed)
@@ -212,6 +212,7 @@ class FlowMatchingEngine:
         cache = self.ddpm_model.prepare_context(c_out) if hasattr(self.ddpm_model, 'prepare_context') else None
         kw = dict(context_cache=cache) if cache is not None else dict(context=c_out)
         samples = fn(zs, self.ddpm_model.forward_with_cfg, return_trajectory=False, cfg_scale=cfg_scale, **kw)[-1]
+        self.last_ode_stats = getattr(fn, 'last_stats', None)        # adaptive solvers: network evaluations, attempted / accepted steps, end time
         return samples.chunk(2, dim=0)[0].contiguous()                                                            # drop the null half
 
     # FlowMatchingEngine.eval_cldm (:554-682): one condition x num_samples; camera[:24]

@@ -91,20 +91,20 @@ class _DinoBlock(nn.Module):
 
 
 class _DinoPatch(nn.Module):
-    def __init__(self, D, P):
+    def __init__(self, D, P, in_chans=3):
         super().__init__()
-        self.proj = nn.Conv2d(3, D, P, P)
+        self.proj = nn.Conv2d(in_chans, D, P, P)
 
 
 class _DinoModel(nn.Module):                 # dinov2 DinoVisionTransformer key layout
-    def __init__(self, D, n, heads, S, P, R, ratio=4):
+    def __init__(self, D, n, heads, S, P, R, ratio=4, in_chans=3):
         super().__init__()
         self.heads, self.image_size, self.patch = heads, S, P
         self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
         self.pos_embed = nn.Parameter(torch.zeros(1, (S // P) ** 2 + 1, D))
         self.register_tokens = nn.Parameter(torch.zeros(1, R, D))
         self.mask_token = nn.Parameter(torch.zeros(1, D))
-        self.patch_embed = _DinoPatch(D, P)
+        self.patch_embed = _DinoPatch(D, P, in_chans)
         self.blocks = nn.ModuleList([_DinoBlock(D, ratio * D) for _ in range(n)])
         self.norm = nn.LayerNorm(D, eps=1e-6)
 
@@ -117,7 +117,8 @@ class _ViTRunner:
         self.s, self.dev, self.ws = spec, dev, Workspace(dev)
         D = spec['D']
         self.zeros = torch.zeros(D, device=dev)
-        kk = 3 * spec['patch'] ** 2
+        self.chans = spec['patch_w'].shape[1]
+        kk = self.chans * spec['patch'] ** 2
         self.kpad = (kk + 63) // 64 * 64
         w = torch.zeros(D, self.kpad)
         w[:, :kk] = spec['patch_w'].detach().reshape(D, kk)
@@ -135,13 +136,13 @@ class _ViTRunner:
     def __call__(self, img):
         s, ws, dev = self.s, self.ws, self.dev
         B, S, P, D, H, R = img.shape[0], s['size'], s['patch'], s['D'], s['heads'], (self.reg.shape[0] if self.reg is not None else 0)
-        assert tuple(img.shape[1:]) == (3, S, S), f"expects {S}x{S} inputs (resize first)"
+        assert tuple(img.shape[1:]) == (self.chans, S, S), f"expects {self.chans} x {S} x {S} inputs (resize first)"
         G = S // P
         Lp, T = G * G, 1 + R + G * G
         M, tpad, Dh = B * T, (T + 63) // 64 * 64, D // H
         assert Dh in (64, 128)
         pm = ws.get('pm', (B * Lp, self.kpad), torch.bfloat16)
-        ops.vit_patchify(img.contiguous().float(), pm, B, S, P, self.kpad)
+        ops.vit_patchify(img.contiguous().float(), pm, B, S, P, self.kpad, self.chans)
         pe = ws.get('pe', (B * Lp, D), torch.float32)
         ops.gemm(pm, self.pw, self.pb, ops.EPI_F32, pe)
         x = ws.get('x', (M, D), torch.float32)
@@ -197,7 +198,7 @@ class _ImageEmbedderBase(nn.Module):
         # UNPINNED against kornia itself.
         return ops.image_preprocess(x, S, getattr(self, 'antialias', True), self.MEAN, self.STD)
 
-    def _run(self, image):
+    def _run(self, image, extra=None):
         if not image.is_cuda:
             raise RuntimeError("ln3diff_amd image embedders run on the HIP device only (no CPU fallback)")
         if image.dim() == 5:
@@ -207,7 +208,10 @@ class _ImageEmbedderBase(nn.Module):
             self._proj_bf = None
             self._epoch = _cache.EPOCH[0]
             _cache.watch_tree(self)
-        return self._runner(self.preprocess(image.float()))
+        x = self.preprocess(image.float())
+        if extra is not None:                             # channels that bypass the image normalisation (Pluecker ray maps)
+            x = torch.cat([x, extra.to(x.dtype)], 1)
+        return self._runner(x)
 
 
 class FrozenOpenCLIPImageEmbedder(_ImageEmbedderBase):
@@ -305,6 +309,69 @@ class FrozenDinov2ImageEmbedder(_ImageEmbedderBase):
 
     def encode(self, image):
         return self(image)
+
+
+class FrozenDinov2ImageEmbedderMVPlucker(FrozenDinov2ImageEmbedder):
+    """Multi-view conditioner of the released MV configs (sgm/modules/encoders/modules.py:871-1111; configs
+    sgm/configs/mv23d-plucker-clipl-compat-fm-lognorm{,-noclip}.yaml: arch vitb, n_cond_frames 4): DINOv2-reg whose patch embedding
+    takes 9 channels - the normalised RGB view followed by its 6 Pluecker ray maps (o x d, d) at the tower's 224 x 224 grid, built
+    from the view's camera (16 c2w + 9 normalised intrinsics).  forward({'img': [B, T, 3, H, W] in [-1, 1], 'c': [B, T, 25]}) ->
+    x_norm_patchtokens of the FIRST n_cond_frames views, [B, n_cond_frames, 256, D] = the MV denoisers' context['concat'].
+    Training-time augmentation (ucg dropout, scale jitter, random camera rotation: aug_c) is not part of sampling and is not built.
+    State-dict keys are the reference embedder's (`model.patch_embed.proj.weight` is [D, 9, 14, 14])."""
+    ARCHS = {'vits': (384, 12, 6), 'vitb': (768, 12, 12), 'vitl': (1024, 24, 16)}
+
+    def __init__(self, arch="vitb", version="dinov2", device="cuda", freeze=True, antialias=True, ucg_rate=0.0, output_tokens=False,
+                 output_cls=False, init_device=None, n_cond_frames=4, enable_bf16=False, modLN=False, aug_c=False,
+                 width=None, layers=None, heads=None, image_size=224, patch_size=14, num_register_tokens=4, **ignored):
+        D, n, H = self.ARCHS[arch]
+        super().__init__(arch=arch, version=version, device=device, freeze=False, antialias=antialias, output_cls=False,
+                         width=width or D, layers=layers or n, heads=heads or H, image_size=image_size, patch_size=patch_size,
+                         num_register_tokens=num_register_tokens)
+        assert not output_cls and not aug_c
+        self.n_cond_frames = n_cond_frames
+        m = self.model
+        self.model = _DinoModel(D=m.cls_token.shape[-1], n=len(m.blocks), heads=m.heads, S=m.image_size, P=m.patch,
+                                R=m.register_tokens.shape[1], in_chans=9)
+        if freeze:
+            self.freeze()
+
+    def get_plucker_ray(self, c):
+        """c [V, 25] -> [V, 6, S, S] (reference :995-1005; one HIP call instead of a Python loop over views)."""
+        return ops.plucker_rays(c, self.model.image_size)
+
+    @torch.no_grad()
+    def forward(self, img_c, no_dropout=False):
+        img, c = img_c['img'], img_c['c']
+        if img.dim() != 5 or c.dim() != 3 or c.shape[-1] != 25 or img.shape[1] < self.n_cond_frames or c.shape[:2] != img.shape[:2]:
+            raise ValueError(f"expects {{'img': [B, T >= {self.n_cond_frames}, 3, H, W], 'c': [B, T, 25]}}; got {tuple(img.shape)} / {tuple(c.shape)}")
+        B, T = img.shape[0], self.n_cond_frames
+        views = img[:, :T].reshape(B * T, *img.shape[2:])
+        rays = self.get_plucker_ray(c[:, :T].reshape(B * T, 25).to(img.device))
+        y, R = self._run(views, extra=rays)
+        tokens = y[:, 1 + R:]
+        return tokens.reshape(B, T, tokens.shape[1], tokens.shape[2]).to(img.dtype)
+
+
+class MV23DConditioner(nn.Module):
+    """GeneralConditioner semantics of the multi-view configs: the MVPlucker embedder's 4-D output is routed to 'concat'
+    ([B, V, 256, D], the MV denoisers' cross-attention context); with a CLIP embedder (the non-noClip config: the FIRST view through
+    FrozenOpenCLIPImageMVEmbedder, :1663-1684) its tokens / pooled vector become 'crossattn' / 'vector'."""
+
+    def __init__(self, dino_mv, clip=None):
+        super().__init__()
+        self.dino_mv, self.clip = dino_mv, clip
+        assert clip is None or clip.output_tokens
+
+    @torch.no_grad()
+    def forward(self, img_c):
+        out = {'concat': self.dino_mv(img_c)}
+        if self.clip is not None:
+            out['crossattn'], out['vector'] = self.clip(img_c['img'][:, 0])
+        return out
+
+    def get_unconditional_conditioning(self, cond):
+        return cond, {k: torch.zeros_like(v) for k, v in cond.items()}
 
 
 class I23DConditioner(nn.Module):

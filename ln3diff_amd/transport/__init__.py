@@ -221,6 +221,7 @@ def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
         h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
         dt = min(100 * h0, h1)
         nfe, steps, accepted = 2, 0, 0
+        trace = []                                          # (t, dt, error ratio) of every attempted step
         t0 = t1 = ts[0]                                    # the interval the interpolant covers (empty before the first step)
         y0i, f0i = y.clone(), k[0]                          # left end of that interval
         y1b, ymid = torch.empty_like(y), torch.empty_like(y)
@@ -245,6 +246,7 @@ def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
                 ratio = rms(err, y, y1b)
                 steps += 1
                 ok = ratio <= 1.0
+                trace.append((ta, dt, ratio))
                 if ok:
                     accepted += 1
                     # _interp_fit(y0, y1, k, dt)
@@ -262,6 +264,6 @@ def _dopri5_sampler(num_steps, atol, rtol, max_steps=100000):
             yo = torch.empty_like(y)
             ops.lincomb(None, [y0i, f0i, cc, cb, ca], [1.0, xq * dti, xq ** 2, xq ** 3, xq ** 4], yo)     # _interp_evaluate
             out.append(yo)
-        sample.last_stats = {'nfe': nfe, 'steps': steps, 'accepted': accepted, 't_end': t1}
+        sample.last_stats = {'nfe': nfe, 'steps': steps, 'accepted': accepted, 't_end': t1, 'h0': min(100 * h0, h1), 'trace': trace}
         return torch.stack(out, 0) if return_trajectory else out[-1][None]
     return sample

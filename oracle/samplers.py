@@ -259,6 +259,7 @@ def flow_ode_dopri5(model_fn, x, num_steps=50, atol=1e-6, rtol=1e-3, stats=None,
     h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
     dt = min(100 * h0, h1)
     nfe, steps, accepted = 2, 0, 0
+    trace, h_first = [], dt
     t0 = t1 = ts[0]
     coef = [y, torch.zeros_like(y), torch.zeros_like(y), torch.zeros_like(y), torch.zeros_like(y)]
     out = y
@@ -274,6 +275,7 @@ def flow_ode_dopri5(model_fn, x, num_steps=50, atol=1e-6, rtol=1e-3, stats=None,
             ratio = rms(err / (atol + rtol * torch.max(y.abs(), y1.abs())))
             steps += 1
             ok = ratio <= 1.0
+            trace.append((float(t1), float(dt), float(ratio)))
             if ok:
                 accepted += 1
                 ymid = y + dt * sum(m * kk for m, kk in zip(MID, ks))
@@ -289,7 +291,7 @@ def flow_ode_dopri5(model_fn, x, num_steps=50, atol=1e-6, rtol=1e-3, stats=None,
         xq = (t_out - t0) / (t1 - t0)
         out = coef[0] + xq * coef[1] + xq ** 2 * coef[2] + xq ** 3 * coef[3] + xq ** 4 * coef[4]
     if stats is not None:
-        stats.update(nfe=nfe, steps=steps, accepted=accepted, t_end=t1)
+        stats.update(nfe=nfe, steps=steps, accepted=accepted, t_end=t1, h0=h_first, trace=trace)
     return out
 
 

@@ -105,3 +105,34 @@ def preprocess(x, S, mean, std, antialias=True):
         x = resize_bicubic_antialias(x, (S, S), antialias)
     x = (x + 1.0) / 2.0
     return (x - torch.tensor(mean).to(x)[None, :, None, None]) / torch.tensor(std).to(x)[None, :, None, None]
+
+
+def plucker_rays(c, S=224):
+    """Pluecker ray maps of posed views: restatement of FrozenDinov2ImageEmbedderMVPlucker.gen_rays / get_plucker_ray
+    (/root/reference/sgm/modules/encoders/modules.py:958-1005).  c [V, 25] = c2w 4x4 (row-major) + normalised intrinsics 3x3 ->
+    [V, 6, S, S] = (o x d, d) per pixel centre.  Pinned against the reference's own methods by tests/golden/make_golden_mv.py."""
+    out = []
+    for cv in c.float():
+        c2w, K = cv[:16].reshape(4, 4), cv[16:]
+        yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float32) + 0.5, torch.arange(S, dtype=torch.float32) + 0.5, indexing='ij')
+        xx, yy = (xx / S - K[2]) / K[0], (yy / S - K[5]) / K[4]
+        d = torch.stack((xx, yy, torch.ones_like(xx)), -1)
+        d = d / d.norm(dim=-1, keepdim=True)
+        d = (c2w[None, :3, :3] @ d.reshape(-1, 3, 1))[..., 0].view(S, S, 3)
+        o = c2w[None, :3, 3].expand(S * S, -1).reshape(S, S, 3)
+        out.append(torch.cat([torch.cross(o, d, dim=-1), d], -1).permute(2, 0, 1))
+    return torch.stack(out, 0)
+
+
+def dinov2_mv_plucker_forward(sd, img_c, heads, n_cond_frames=4, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), size=224):
+    """FrozenDinov2ImageEmbedderMVPlucker.forward (:1084-1111) for images already at the tower's size: the first n_cond_frames views,
+    (x + 1) / 2 and mean / std on RGB, the 6 Pluecker maps appended UNNORMALISED (9 input channels), x_norm_patchtokens back as
+    [B, T, L, D].  sd: dinov2 state dict with a 9-channel patch_embed.proj.weight."""
+    img, c = img_c['img'].float(), img_c['c'].float()
+    B, T = img.shape[0], n_cond_frames
+    x = img[:, :T].reshape(B * T, *img.shape[2:])
+    assert x.shape[-1] == size and x.shape[-2] == size, "resize first (resize_bicubic_antialias)"
+    x = ((x + 1.0) / 2.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    x = torch.cat([x, plucker_rays(c[:, :T].reshape(B * T, 25), size)], 1)
+    _, tokens = dinov2_forward(sd, x, heads)
+    return tokens.reshape(B, T, tokens.shape[1], tokens.shape[2])

@@ -16,7 +16,8 @@ NULL_CALLS = {
     'ln3d_render_triplane': (N, N),
     'ln3d_embed_tokens': (N, N, N, N, 1, 1, 4, 1, N),
     'ln3d_layernorm_f32': (N, N, N, N, I64(1), 128, F(1e-5), N),
-    'ln3d_vit_patchify': (N, N, 1, 224, 14, 640, N),
+    'ln3d_vit_patchify': (N, N, 1, 224, 14, 640, 3, N),
+    'ln3d_plucker_rays': (N, N, 1, 224, N),
     'ln3d_vit_assemble': (N, N, N, N, N, 1, 1, 0, 128, N),
     'ln3d_image_preprocess': (N, N, N, 1, 3, 8, 8, 4, 1, N, N, N),
     'ln3d_rmsnorm_heads_bf16': (N, N, I64(1), 64, 64, F(1e-5), N),

@@ -64,3 +64,31 @@ def test_config4_i23d_512_24cams_mesh_end_to_end(hip_lib, tmp_path):
     assert frames.shape == (24, 3, 512, 512) and np.isfinite(frames).all() and np.abs(frames).max() <= 1.0 + 2e-3
     assert depth.shape == (24, 1, 512, 512) and np.isfinite(depth).all()
     assert os.path.exists(tmp_path / "mesh_sample0.obj")
+
+
+def test_multiview_image_path_runs_the_plucker_conditioner(hip_lib, tmp_path):
+    """r4 (f)3: --image_path with a multi-view denoiser encodes posed views through FrozenDinov2ImageEmbedderMVPlucker (synthetic
+    embedder checkpoint in the reference's own key layout) instead of asking for --cond_path tensors; the run records its source."""
+    import json
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedderMVPlucker
+    from ln3diff_amd.synth import synth_vit_state_dict, synth_input
+    emb = FrozenDinov2ImageEmbedderMVPlucker(arch='vitb', n_cond_frames=2, device='cpu')
+    sd = {'model.' + k: v for k, v in synth_vit_state_dict({k[6:]: tuple(v.shape) for k, v in emb.state_dict().items()}, 3).items()}
+    torch.save(sd, tmp_path / "embedder_FrozenDinov2ImageEmbedderMVPlucker0000001.pt")
+    cams = np.zeros((3, 25), np.float32)
+    for t in range(3):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = (0.3 * t, 0.1, -1.8)
+        cams[t, :16], cams[t, 16:] = m.reshape(-1), (1.1, 0, 0.5, 0, 1.1, 0.5, 0, 0, 1)
+    np.savez(tmp_path / "views.npz", img=synth_input('mvimg', (3, 3, 224, 224), 5).clamp(-1, 1).numpy(), c=cams)
+    flags = ("--dit_model_arch DiT-PixArt-MV-L/2 --i23d true --trainer_name flow_matching --num_mv_views 2 --mv_dino_arch vitb --num_samples 1 "
+             "--sample_steps 3 --ode_method euler --unconditional_guidance_scale 4.0 --image_size 32 --num_views 2 "
+             f"--image_path {tmp_path}/views.npz --dino_checkpoint {tmp_path}/embedder_FrozenDinov2ImageEmbedderMVPlucker0000001.pt --logdir {tmp_path}/out")
+    lat = run(create_argparser(True).parse_args(flags.split()))
+    assert lat.shape == (1, 12, 32, 32) and torch.isfinite(lat).all()
+    meta = json.load(open(tmp_path / "out" / "args.json"))
+    assert meta['conditioning'].startswith('MV23DConditioner(') and meta['weights']['dit'] == 'synthetic'
+    # a different view set conditions differently
+    np.savez(tmp_path / "views2.npz", img=synth_input('mvimg', (3, 3, 224, 224), 6).clamp(-1, 1).numpy(), c=cams)
+    lat2 = run(create_argparser(True).parse_args(flags.replace("views.npz", "views2.npz").replace("/out", "/out2").split()))
+    assert not torch.equal(lat, lat2)

@@ -222,3 +222,21 @@ def test_oracle_i23d_multiview_noclip_matches_reference_golden():
     y = odit.i23d_mv_noclip_forward(sd, synth_input('x', (2, 12, 32, 32), 5), torch.from_numpy(g['t']),
                                     {'concat': synth_input('mv', (2, 4, 256, 768), 5)}, 2)
     assert rel_l2(y, g['y']) < 1e-4
+
+
+def test_oracle_multiview_conditioner_matches_goldens():
+    """r4 (f)3: Pluecker ray maps against the REFERENCE's own get_plucker_ray (fixture of tests/golden/make_golden_mv.py, sub-sampled),
+    the 9-channel DINOv2-reg conditioner against the transformers-pinned fixture at the tiny size."""
+    import json
+    from oracle import vit_image as ovit
+    from ln3diff_amd.synth import synth_vit_state_dict
+    g = golden('mv_plucker_rays')
+    st = int(g['stride'])
+    rays = ovit.plucker_rays(torch.from_numpy(g['c']), 224)
+    assert rays.shape == (6, 6, 224, 224) and rel_l2(rays[:, :, ::st, ::st], g['rays']) < 1e-6
+    g = golden('mv_plucker_tiny')
+    sh = {k: tuple(v) for k, v in json.loads(str(g['manifest'])).items()}
+    T, S = int(g['n_cond_frames']), int(g['size'])
+    img_c = {'img': synth_input('mvimg', (2, T + 1, 3, S, S), 7).clamp(-1, 1), 'c': torch.from_numpy(g['c'])}
+    tok = ovit.dinov2_mv_plucker_forward(synth_vit_state_dict(sh, 0), img_c, int(g['heads']), n_cond_frames=T, size=S)
+    assert tok.shape[:2] == (2, T) and rel_l2(tok[:, :, ::int(g['tok_stride'])], g['tokens']) < 1e-5

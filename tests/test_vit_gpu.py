@@ -59,6 +59,43 @@ def test_dinov2_tower_vs_golden(hip_lib, name, B):
     assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
 
 
+def test_plucker_ray_kernel_vs_reference_fixture(hip_lib):
+    """ln3d_plucker_rays against the reference's own get_plucker_ray (tests/golden/mv_plucker_rays.npz, every 7th pixel)."""
+    from ln3diff_amd import ops
+    g = golden('mv_plucker_rays')
+    st = int(g['stride'])
+    rays = ops.plucker_rays(torch.from_numpy(g['c']).cuda(), 224)
+    assert rays.shape == (6, 6, 224, 224)
+    assert rel_l2(rays[:, :, ::st, ::st].cpu(), g['rays']) < 1e-6
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 2), ("vitb14reg", 1)])
+def test_multiview_plucker_conditioner_vs_golden(hip_lib, name, B):
+    """r4 (f)3: FrozenDinov2ImageEmbedderMVPlucker (the released mv23d-plucker configs: DINOv2 ViT-B/14-reg, 9-channel patch embedding,
+    4 condition views) on the HIP kernels against the transformers-pinned oracle fixture; one view more than n_cond_frames is
+    passed (the conditioner takes the first n_cond_frames); reference key layout."""
+    from ln3diff_amd.sgm.image_encoders import FrozenDinov2ImageEmbedderMVPlucker, MV23DConditioner
+    g = golden(f'mv_plucker_{name}')
+    sh = _shapes(g)
+    D = sh['cls_token'][-1]
+    n = 1 + max(int(k.split('.')[1]) for k in sh if k.startswith('blocks.'))
+    S, T = int(g['size']), int(g['n_cond_frames'])
+    m = FrozenDinov2ImageEmbedderMVPlucker(arch='vitb', n_cond_frames=T, width=D, layers=n, heads=int(g['heads']), image_size=S,
+                                           num_register_tokens=sh['register_tokens'][1])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {'model.' + k: v for k, v in sh.items()}
+    assert m.state_dict()['model.patch_embed.proj.weight'].shape[1] == 9
+    m.load_state_dict({'model.' + k: v for k, v in synth_vit_state_dict(sh, 0).items()}, strict=True)
+    img_c = {'img': synth_input('mvimg', (B, T + 1, 3, S, S), 7).clamp(-1, 1).cuda(), 'c': torch.from_numpy(g['c']).cuda()}
+    out = MV23DConditioner(m)(img_c)
+    tok = out['concat']
+    assert set(out) == {'concat'} and tok.shape == (B, T, (S // 14) ** 2, D)
+    e = rel_l2(tok[:, :, ::int(g['tok_stride'])].cpu(), torch.from_numpy(g['tokens']).float())
+    print('mv plucker conditioner', name, e)
+    assert e < 2e-2, e
+    with pytest.raises(ValueError):
+        m({'img': img_c['img'][:, :T - 1], 'c': img_c['c'][:, :T - 1]})           # fewer views than n_cond_frames
+
+
 def test_image_embedder_resizes_other_input_sizes(hip_lib):
     """preprocess (sgm/modules/encoders/modules.py:633-645,802-814) is ONE HIP call (ln3d_image_preprocess): kornia-style Gaussian
     pre-blur when a side shrinks + bicubic / align_corners resize + (x + 1) / 2 + mean / std.  Checked against the CPU restatement
