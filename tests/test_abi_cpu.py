@@ -47,7 +47,7 @@ NULL_CALLS = {
     'ln3d_groupnorm_swish': (N, N, N, N, N, 1, 64, 64, 32, F(1e-6), 1, N),
     'ln3d_im2col3x3': (N, N, 1, 8, 8, 64, 1, 576, N),
 }
-NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable'}      # pure host queries
+NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_gemm_norm_fusable'}      # pure host queries
 
 
 def test_every_entry_point_rejects_missing_buffers(hip_lib):
