@@ -207,6 +207,19 @@ __device__ __forceinline__ float softplus_log2(float x) {   // log2(1 + 2^x); x 
   return x > 28.853900817779268f ? x : y;                     // torch softplus threshold 20, in log2 units
 }
 
+// torch softplus (beta 1, threshold 20) and exp(-t) of the ray-marcher on the transcendental unit (r4).  The libm forms
+// (log1pf(expf(x)), expf) were ~130 + ~25 dependent vector instructions each, three times per ray and lane, all on the per-ray
+// critical path.  softplus(x) = max(x, 0) + log1p(e), e = exp(-|x|); log1p with Kahan's correction for the rounding of 1 + e
+// (log(u) * e / (u - 1), u = fl(1 + e)): ~2 ulp, the images move by <= 1e-6 against the fp32 oracle (tests/test_render_gpu.py).
+__device__ __forceinline__ float softplus20_hw(float x) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
+  const float u = 1.0f + e, d = u - 1.0f;
+  const float l = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+  const float l1p = d == 0.f ? e : l * (e * __builtin_amdgcn_rcpf(d));
+  return x > 20.0f ? x : fmaxf(x, 0.f) + l1p;
+}
+__device__ __forceinline__ float exp_neg_hw(float t) { return __builtin_amdgcn_exp2f(t * -1.4426950408889634f); }   // exp(-t)
+
 __device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, char* wl, const char* cimg,
                                         float px, float py, float pz, int lane, float rgb[3], float& sigma) {
   const int g = lane >> 3, c4 = lane & 7;
@@ -415,6 +428,11 @@ __device__ __forceinline__ float wave_total(float v) {               // sum over
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_sum(v, 0)), 63));
 }
 
+// cnt += bit `lane` of mask: the mask goes in as the carry of v_addc (one vector instruction; shifting the 64-bit mask per lane costs four)
+__device__ __forceinline__ void add_mask(int& cnt, uint64_t m) {
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(cnt) : "s"(m) : "vcc");
+}
+
 // the workgroup's copy of the decoder image (built once per launch by render_init_kernel) behind the 4 wave regions
 __device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const float* dec_img) {
   char* cimg = lds_bytes + 4 * WAVE_LDS_BYTES;
@@ -483,8 +501,8 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
     float wgt;
     {
       const float dl = zn - zc;
-      const float dm = softplus20((sigc + sn) * 0.5f - 1.0f);
-      float alpha = 1.0f - expf(-(dm * dl));
+      const float dm = softplus20_hw((sigc + sn) * 0.5f - 1.0f);
+      float alpha = 1.0f - exp_neg_hw(dm * dl);
       if (lane == NS - 1) alpha = 0.f;
       const float T = wave_excl_prod(lane == NS - 1 ? 1.0f : (1.0f - alpha + 1e-10f), lane);
       wgt = alpha * T;                                       // lane 63: 0 (unused)
@@ -545,17 +563,44 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
     // Total order: by depth; equal depths: coarse before fine, then by lane.  The coarse depths are NOT assumed to be sorted by
     // lane: on a ray that only grazes the box (t1 - t0 ~ 1e-5) rounding can swap two neighbours, and with a fine sample between
     // them "rank = lane + ..." collided with it (garbage weights on ~1 ray per million at 512^2; the reference sorts for real).
-    int rc = 0, rf = 0;
+    int rc, rf;
+    // r4: the rank counting was 1 956 of the 4 860 vector instructions of a ray (four compare classes x 128 elements with tie rules).
+    // With the coarse depths in lane order (every ray but the grazing ones) the coarse self-rank IS the lane and #(zc <= zf) is an
+    // upper bound in the sorted LDS copy (7 dependent reads); what is left per fine element k is one compare for the coarse lanes
+    // and the (<, ==) pair for the fine ones, accumulated through the carry-in of v_addc (the tie rule "k < lane" is a constant
+    // lane mask on the scalar side).  Identical ranks by construction; rays with a swapped neighbour pair or a NaN take the full count.
+    const bool in_order = (zc <= zn) && (zf == zf);
+    if (__builtin_amdgcn_ballot_w64(!in_order) == 0ull) {
+      int pos = 0;
+#pragma unroll
+      for (int s2 = 32; s2 >= 1; s2 >>= 1) pos += (zc_s[pos + s2 - 1] <= zf) ? s2 : 0;
+      pos += (zc_s[pos] <= zf) ? 1 : 0;
+      rc = lane; rf = pos;
+#define RANK_STEP(av, k)                                                                                       \
+      {                                                                                                        \
+        add_mask(rc, __builtin_amdgcn_ballot_w64((av) < zc));                                                  \
+        const uint64_t lt_ = __builtin_amdgcn_ballot_w64((av) < zf), eq_ = __builtin_amdgcn_ballot_w64((av) == zf); \
+        add_mask(rf, lt_ | (eq_ & ((k) < 63 ? (~0ull << (((k) + 1) & 63)) : 0ull)));                           \
+      }
+#pragma unroll
+      for (int k = 0; k < NS; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
+        RANK_STEP(a.x, k + 0) RANK_STEP(a.y, k + 1) RANK_STEP(a.z, k + 2) RANK_STEP(a.w, k + 3)
+      }
+#undef RANK_STEP
+    } else {
+      rc = 0; rf = 0;
 #pragma unroll 4
-    for (int k = 0; k < NS; k += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
-      const float4 b = *reinterpret_cast<const float4*>(zc_s + k);
-      rc += (a.x < zc) + (a.y < zc) + (a.z < zc) + (a.w < zc);
-      rc += (b.x < zc || (b.x == zc && k + 0 < lane)) + (b.y < zc || (b.y == zc && k + 1 < lane)) +
-            (b.z < zc || (b.z == zc && k + 2 < lane)) + (b.w < zc || (b.w == zc && k + 3 < lane));
-      rf += (b.x <= zf) + (b.y <= zf) + (b.z <= zf) + (b.w <= zf);
-      rf += (a.x < zf || (a.x == zf && k + 0 < lane)) + (a.y < zf || (a.y == zf && k + 1 < lane)) +
-            (a.z < zf || (a.z == zf && k + 2 < lane)) + (a.w < zf || (a.w == zf && k + 3 < lane));
+      for (int k = 0; k < NS; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
+        const float4 b = *reinterpret_cast<const float4*>(zc_s + k);
+        rc += (a.x < zc) + (a.y < zc) + (a.z < zc) + (a.w < zc);
+        rc += (b.x < zc || (b.x == zc && k + 0 < lane)) + (b.y < zc || (b.y == zc && k + 1 < lane)) +
+              (b.z < zc || (b.z == zc && k + 2 < lane)) + (b.w < zc || (b.w == zc && k + 3 < lane));
+        rf += (b.x <= zf) + (b.y <= zf) + (b.z <= zf) + (b.w <= zf);
+        rf += (a.x < zf || (a.x == zf && k + 0 < lane)) + (a.y < zf || (a.y == zf && k + 1 < lane)) +
+              (a.z < zf || (a.z == zf && k + 2 < lane)) + (a.w < zf || (a.w == zf && k + 3 < lane));
+      }
     }
     // five planes of 128 ({z}, {sigma}, {r}, {g}, {b} by rank): lane i then reads its elements 2i, 2i+1 as ONE 8-byte access per plane
     // and takes element 2i+2 from lane i+1 over DPP (r2's [rank][5] records cost 15 reads with 2-way bank conflicts each)
@@ -573,10 +618,10 @@ __global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
     wave_sync();
     float a0, a1;
     {
-      const float dm0 = softplus20((e[0][1] + e[1][1]) * 0.5f - 1.0f);
-      a0 = 1.0f - expf(-(dm0 * (e[1][0] - e[0][0])));
-      const float dm1 = softplus20((e[1][1] + e[2][1]) * 0.5f - 1.0f);
-      a1 = lane == NS - 1 ? 0.f : 1.0f - expf(-(dm1 * (e[2][0] - e[1][0])));
+      const float dm0 = softplus20_hw((e[0][1] + e[1][1]) * 0.5f - 1.0f);
+      a0 = 1.0f - exp_neg_hw(dm0 * (e[1][0] - e[0][0]));
+      const float dm1 = softplus20_hw((e[1][1] + e[2][1]) * 0.5f - 1.0f);
+      a1 = lane == NS - 1 ? 0.f : 1.0f - exp_neg_hw(dm1 * (e[2][0] - e[1][0]));
     }
     const float f0 = 1.0f - a0 + 1e-10f, f1 = lane == NS - 1 ? 1.0f : (1.0f - a1 + 1e-10f);
     const float Ts = wave_excl_prod(f0 * f1, lane);
