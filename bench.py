@@ -28,16 +28,16 @@ def _sha16(rel):
 
 
 def pmc_traffic(key):
-    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r3_pmc.json:
+    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r4_pmc.json:
     FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes; bench.py cannot run the profiler on itself).  An entry is
     only valid for the kernel source it was measured on: it carries the sha256 of the .hip file, and a different source on disk
     yields null plus the reason instead of a stale number."""
-    path = os.path.join(ROOT, 'profiles', 'r3_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r4_pmc.json')
     if not os.path.exists(path):
-        return None, 'profiles/r3_pmc.json missing'
+        return None, 'profiles/r4_pmc.json missing'
     ent = json.load(open(path)).get(key)
     if ent is None:
-        return None, 'no PMC entry for %s in profiles/r3_pmc.json' % key
+        return None, 'no PMC entry for %s in profiles/r4_pmc.json' % key
     cur = _sha16(ent['hip'])
     if cur != ent['sha16']:
         return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/pmc_traffic.sh' % (ent['hip'], cur, ent['sha16'])
@@ -476,7 +476,13 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl, "global_batch": Bt, "views": args.views, "res": args.res,
-                       "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world},
+                       "parallelism": "dp%d (independent samples per rank, no in-loop collective)" % world,
+                       # the released samplers' unconditional context is all zeros: that half's cross-attention is a per-layer constant
+                       # and is folded (exact algebra, tests/test_dit_gpu.py / test_i23d_gpu.py); LN3D_NO_UC_FOLD=1 gives the unfolded figure
+                       "cfg_uncond": ("zero unconditional context (released configuration), " +
+                                      ("NOT folded (LN3D_NO_UC_FOLD=1)" if os.environ.get("LN3D_NO_UC_FOLD") else
+                                       "cross-attention of the unconditional half folded; unfolded figure: profiles/r4_bench_%s_nofold.json"
+                                       % ("i23d" if i23d else "t23d")))},
             "finite": ok,
             "ranks_seen": seen, "collectives": parallel.collective_info(), "bcast_ms": round(bcast_ms, 2),
             "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps if (not i23d or args.ode_method == "euler") else -1),

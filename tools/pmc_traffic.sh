@@ -1,9 +1,9 @@
 # HBM / fabric traffic per launch of the three roofline kernels at bench.py's shapes (GPU box): FETCH_SIZE and WRITE_SIZE in
-# SEPARATE rocprofv3 --pmc passes (MI355X_MICROARCH.md's HBM section), written as gpurun_out/r3_pmc.json with the sha256 of the
-# kernel source each number belongs to.  Copy that file to profiles/r3_pmc.json: bench.py reads it (pmc_traffic()).
+# SEPARATE rocprofv3 --pmc passes (MI355X_MICROARCH.md's HBM section), written as gpurun_out/r4_pmc.json with the sha256 of the
+# kernel source each number belongs to.  Copy that file to profiles/r4_pmc.json: bench.py reads it (pmc_traffic()).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r3_pmc
+OUT=$R/gpurun_out/r4_pmc
 rm -rf $OUT; mkdir -p $OUT
 run() { n=$1; c=$2; shift 2; timeout 180 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$n.$c -- python $R/tools/pmc_one.py "$@" > /dev/null 2>&1; }
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -40,5 +40,5 @@ for k, e in res.items():
     e["traffic_bytes"] = int(f * 1024 * 2 + w * 1024)
     e["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB, FETCH x2 gfx950 correction), tools/pmc_traffic.sh"
     print("%-36s fetch %.1f MB (x2 corrected) write %.1f MB  -> %.1f MB / launch" % (k, f * 2 / 1024, w / 1024, e["traffic_bytes"] / 1e6))
-json.dump(res, open(R + "/gpurun_out/r3_pmc.json", "w"), indent=1)
+json.dump(res, open(R + "/gpurun_out/r4_pmc.json", "w"), indent=1)
 PY
