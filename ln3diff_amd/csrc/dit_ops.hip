@@ -18,17 +18,19 @@ struct NormP {
 // its first D % 512 / 8 lanes.  r4: this is the only norm + modulate kernel (r1's float2 and r2's float4 variants served the widths
 // that are not multiples of 512 - DiT-XL/2's 1152 ran 1.6x slower per byte than the 1024-wide rows).  One row per wave: r3 measured
 // 14.0 / 17.2 / 20.4 us at 1 / 2 / 4 rows per wave (12288 x 1024).
+// MV8 = 512-feature chunks held per lane set; FULL = D is a multiple of 512: every chunk test is wave-uniform.  (r4: with the per-lane
+// test of the general form on the D = 1024 path every row load sat behind its own branch + vmcnt(0): 14.9 -> 16.9 us at 12288 x 1024.)
+template <int MV8, bool FULL>
 __global__ __launch_bounds__(256) void norm_modulate_kernel(NormP p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
-  constexpr int MV8 = (128 * MAXV + 511) / 512;
   const float* xr = p.x + row * p.D;
   float4 v[MV8][2], sc[MV8][2], sh[MV8][2];
   bool ok[MV8];
 #pragma unroll
   for (int i = 0; i < MV8; ++i) {
-    ok[i] = i * 512 + lane * 8 < p.D;
+    ok[i] = FULL ? (i * 512 < p.D) : (i * 512 + lane * 8 < p.D);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       v[i][k] = ok[i] ? *reinterpret_cast<const float4*>(xr + i * 512 + lane * 8 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -113,7 +115,11 @@ extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
   p.shift = a->shift; p.scale = a->scale; p.mod_rows = a->mod_rows > 0 ? a->mod_rows : 1; p.mod_ld = a->mod_ld;
   p.shift_table = a->shift_table; p.scale_table = a->scale_table;
   p.rows_in = a->rows_in > 0 ? a->rows_in : (int)a->rows; p.rows_out = a->rows_out > 0 ? a->rows_out : p.rows_in;
-  hipLaunchKernelGGL(norm_modulate_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)((a->rows + 3) / 4));
+  constexpr int MVG = (128 * MAXV + 511) / 512;
+  if (a->D % 512 == 0 && a->D <= 1024) hipLaunchKernelGGL((norm_modulate_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (a->D % 512 == 0) hipLaunchKernelGGL((norm_modulate_kernel<MVG, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((norm_modulate_kernel<MVG, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   return ln3d_check_launch();
 }
 
