@@ -130,17 +130,20 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     from ln3diff_amd import ops
     Nq = Nq or N
     Dh_true = Dh
-    Dh = 64 if Dh <= 64 else 128                   # head sizes like DiT-XL/2's 72 run in zero-padded 128-wide heads (as in the model)
+    Dh = 64 if Dh <= 64 else 128                   # head sizes like DiT-XL/2's 72 sit in zero-padded 128-wide rows (as in the model)
     q = torch.randn(n_net, H, Nq, Dh, device=dev).to(torch.bfloat16)
     k = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
     vt = torch.randn(n_net, H, Dh, N, device=dev).to(torch.bfloat16)
-    o = torch.empty(n_net, Nq, H * Dh, device=dev, dtype=torch.bfloat16)
+    dt = Dh_true if Dh_true != Dh else 0            # as the model calls it: true head size, compact [.., H * Dh_true] output rows
+    if dt:
+        q[..., dt:] = 0; k[..., dt:] = 0; vt[:, :, dt:, :] = 0
+    o = torch.empty(n_net, Nq, H * (dt or Dh), device=dev, dtype=torch.bfloat16)
     for _ in range(3):
-        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh)
+        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh, scale=Dh_true ** -0.5, dh_true=dt)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh)
+        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh, scale=Dh_true ** -0.5, dh_true=dt)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -149,7 +152,7 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     kres = (N % 256 == 0 and 512 <= N <= 768 and Nq % 256 == 0 and Dh == 64 and n_net * H >= 256 and os.environ.get('LN3D_ATTN_V') in (None, '', '4'))
     stream = (N % 256 == 0 and Dh == 64 and not kres and os.environ.get('LN3D_ATTN_V') != '2')
     name = ("attn_kres_kernel (K resident in LDS, V^T ring, row sums on the matrix pipe)" if kres else
-            "attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<%d> (tiled, %d-wide heads padded to %d)" % (Dh, Dh_true, Dh))
+            "attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<%d, DT %d> (tiled ring kernel; %d-wide heads in %d-wide rows, the padding skipped)" % (Dh, Dh_true, Dh_true, Dh))
     traffic, src = pmc_traffic("attention_%dx%dx%dx%d" % (n_net * H, Nq, N, Dh))
     return {"kernel": name + " - DiT self-attention, %d queries x %d keys" % (Nq, N), "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0,
             "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": traffic, "traffic_source": src}
