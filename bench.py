@@ -321,10 +321,11 @@ def golden_check(latent0, i23d, arch, sample_steps):
     """Sample 0 of the timed run (global sample 0: the golden's inputs, weights and sampler settings) against the final latent of
     the reference's own B = 1 loop (tests/golden/full_edm_ditl2_250.npz / full_flow_pixartl2_euler50.npz, made by
     tests/golden/make_golden_full.py in the build container): what ran at the benchmarked batch geometry IS the reference's
-    computation, not merely something finite.  Only the two baseline configurations have a fixture."""
+    computation, not merely something finite.  configs[1], configs[2] and (r4) configs[3]'s DiT-XL/2 have a fixture."""
     import numpy as np
     name = ('full_flow_pixartl2_euler50' if (i23d and arch == 'DiT-PixArt-L/2' and sample_steps == 50) else
-            'full_edm_ditl2_250' if (not i23d and arch == 'DiT-L/2' and sample_steps == 250) else None)
+            'full_edm_ditl2_250' if (not i23d and arch == 'DiT-L/2' and sample_steps == 250) else
+            'full_edm_ditxl2_250' if (not i23d and arch == 'DiT-XL/2' and sample_steps == 250) else None)
     path = os.path.join(ROOT, 'tests', 'golden', (name or '') + '.npz')
     if name is None or not os.path.exists(path):
         return {"fixture": None, "reason": "no golden fixture for this arch / step count"}

@@ -53,6 +53,9 @@ static_assert(MAX_GROUPS >= 1024, "room for the per-call range records");
 #ifndef RENDER_OCC
 #define RENDER_OCC 3
 #endif
+#ifndef RENDER_WPB
+#define RENDER_WPB 4          // wavefronts (= rays in flight) per workgroup of render_kernel; they share one LDS copy of the decoder image
+#endif
 #ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
 #define LN3D_RENDER_ABL 0
 #endif
@@ -434,14 +437,15 @@ __device__ __forceinline__ void add_mask(int& cnt, uint64_t m) {
 }
 
 // the workgroup's copy of the decoder image (built once per launch by render_init_kernel) behind the 4 wave regions
-__device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const float* dec_img) {
-  char* cimg = lds_bytes + 4 * WAVE_LDS_BYTES;
+__device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const float* dec_img, int nwpb = 4) {
+  char* cimg = lds_bytes + nwpb * WAVE_LDS_BYTES;
   const uint4* src = reinterpret_cast<const uint4*>(dec_img);
   for (int i = threadIdx.x; i < DEC_BYTES / 16; i += blockDim.x) reinterpret_cast<uint4*>(cimg)[i] = src[i];
   __syncthreads();
   return cimg;
 }
 #define RENDER_LDS_BYTES (4 * WAVE_LDS_BYTES + DEC_BYTES)
+#define RENDER_K_LDS_BYTES (RENDER_WPB * WAVE_LDS_BYTES + DEC_BYTES)
 
 __device__ __forceinline__ void flush_depth_range(uint32_t* scal_u, int grp, float dmin_l, float dmax_l, int lane) {
   if (grp < 0) return;
@@ -453,19 +457,19 @@ __device__ __forceinline__ void flush_depth_range(uint32_t* scal_u, int grp, flo
   }
 }
 
-__global__ __launch_bounds__(256, RENDER_OCC) void render_kernel(RenderP p) {
+__global__ __launch_bounds__(64 * RENDER_WPB, RENDER_OCC) void render_kernel(RenderP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec);
+  const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec, RENDER_WPB);
   float* feat = lds + wid * WAVE_LDS_FLOATS;       // 2048 floats; reused for cdf/bins/merge arrays between shading passes
   char* wl = reinterpret_cast<char*>(feat);
   const int M = p.res * p.res;
   const int64_t nrays = (int64_t)p.V * M;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t nwaves = (int64_t)gridDim.x * RENDER_WPB;
   float dmin_l = 3.0e38f, dmax_l = -3.0e38f;
   int cur_grp = -1;
 
-  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < nrays; ray += nwaves) {
+  for (int64_t ray = (int64_t)blockIdx.x * RENDER_WPB + wid; ray < nrays; ray += nwaves) {
     const int v = (int)(ray / M), pix = (int)(ray % M);
     float o[3], d[3];
     if (p.ray_o) {
@@ -680,14 +684,14 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   const int64_t nrays = (int64_t)a->V * a->res * a->res;
   static AttrOnce attr_once;
   if (attr_once.need()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_K_LDS_BYTES);
   }
   hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, groups, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
   hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
-  int64_t blocks = (nrays + 3) / 4;
-  const int64_t cap = 256 * 8;
+  int64_t blocks = (nrays + RENDER_WPB - 1) / RENDER_WPB;
+  const int64_t cap = 256 * 8 * 4 / RENDER_WPB;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, s, p);
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(64 * RENDER_WPB), RENDER_K_LDS_BYTES, s, p);
   hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays, (int64_t)p.vpc * a->res * a->res);
   return ln3d_check_launch();
 }

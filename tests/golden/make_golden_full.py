@@ -2,10 +2,11 @@
 """Full-size golden vectors (VERDICT r1 "weak" item 1): sequential parity at the benchmarked model sizes, produced by the
 REFERENCE's own Python in the build container (see make_golden.py for the rules; the reference does not travel).
 
-    python tests/golden/make_golden_full.py [full_edm] [full_flow] [render_full] [chain] [f4]
+    python tests/golden/make_golden_full.py [full_edm] [full_edm_xl2] [full_flow] [render_full] [chain] [f4]
 
   full_edm    DiT-L/2 T23D, EulerEDMSampler(250) + DiscreteDenoiser + VanillaCFG(6.5), B = 1 (network batch 2): final
               latent and three trajectory points.  ~2 x 8 min on 8 cores (reference + oracle).
+  full_edm_xl2  the same loop on DiT-XL/2 (configs[3]), reference only: final latent.  ~15 min.
   full_flow   DiT-PixArt-L/2 I23D, transport Sampler.sample_ode('euler', 50) with forward_with_cfg(4.0), B = 1: final latent.
   render_full one 128^2 and one 256^2 view of the reference Triplane.forward (fp16, sub-sampled) + full-image statistics.
   chain       BASELINE configs[1] end to end on the tiny models (a20): z(seed 41) -> EulerEDM(10)+CFG -> latent * 0.96806 ->
@@ -63,6 +64,32 @@ def sec_full_edm():
     print(f'  oracle loop {time.time() - t0:.0f}s')
     check('DiT-L/2 EulerEDM-250 final latent', y_or, y_ref, 5e-4)
     save('full_edm_ditl2_250', final=y_ref, first=trace[0], s50=trace[50], s125=trace[125], s200=trace[200])
+
+
+def sec_full_edm_xl2():
+    """r4: configs[3]'s denoiser through the WHOLE 250-step loop (r3 pinned DiT-XL/2 for 10 steps only): reference loop only, the
+    oracle is already checked against it on this network in make_golden_geom.py xl2_edm10.  bench.py --arch DiT-XL/2 compares the
+    latent of its timed run with `final` (same inputs: seed 41, synthetic weights 0)."""
+    print('== DiT-XL/2 T23D (configs[3]): EulerEDM 250 + CFG 6.5, B=1 (reference sgm sampler)')
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    hidden, depth, heads = odit.DIT_CONFIGS['DiT-XL/2']
+    m = mg.build_t23d(hidden, depth, heads)
+    load_synth(m, 0)
+    z = synth_input('z', (1, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (1, 77, 768), 41), 'vector': synth_input('v', (1, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    steps = 250
+    sampler = EulerEDMSampler(discretization_config=dc, num_steps=steps,
+                              guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG',
+                                             'params': {'scale': 6.5}}, device='cpu')
+    den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                           num_idx=1000, discretization_config=dc, do_append_zero=False, quantize_c_noise=True, flip=True)
+    t0 = time.time()
+    y_ref = sampler(lambda x, s, c: den(lambda xx, t, cc, **kw: m(xx, t, cc), x, s, c), z.clone(), cond, uc)
+    print(f'  reference loop {time.time() - t0:.0f}s; final std {float(y_ref.std()):.3f} finite {bool(torch.isfinite(y_ref).all())}')
+    save('full_edm_ditxl2_250', final=y_ref)
 
 
 def sec_full_flow():
@@ -237,7 +264,7 @@ def sec_f4():
         del m, sd
 
 
-SECTIONS = {'full_edm': sec_full_edm, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain, 'f4': sec_f4}
+SECTIONS = {'full_edm': sec_full_edm, 'full_edm_xl2': sec_full_edm_xl2, 'full_flow': sec_full_flow, 'render_full': sec_render_full, 'chain': sec_chain, 'f4': sec_f4}
 
 if __name__ == '__main__':
     for s in (sys.argv[1:] or list(SECTIONS)):

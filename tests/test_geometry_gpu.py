@@ -124,6 +124,22 @@ def test_xl2_edm10_vs_reference_golden(hip_lib):
     assert e8 < 1e-2, e8
 
 
+def test_xl2_edm250_vs_reference_golden(hip_lib):
+    """r4: configs[3]'s denoiser through the WHOLE 250-step EulerEDM + CFG loop against the reference's own B = 1 run (the fixture
+    bench.py --arch DiT-XL/2 checks its timed latent against); DiT-L/2 measures 1.7e-3 on the same loop."""
+    from ln3diff_amd.sgm.sampling import EulerEDMSampler, DiscreteDenoiser, VanillaCFG
+    from ln3diff_amd.synth import synth_input
+    g = golden('full_edm_ditxl2_250')
+    m = _t23d('DiT-XL/2')
+    z = synth_input('z', (1, 12, 32, 32), 41).cuda()
+    cond = {'crossattn': synth_input('c', (1, 77, 768), 41).cuda()}
+    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z, cond, uc)
+    e = rel_l2(y.cpu(), g['final'])
+    print('DiT-XL/2 EulerEDM-250 final latent:', e)
+    assert e < 1e-2, e
+
+
 def test_render_512_vs_reference_golden(hip_lib):
     from test_render_gpu import _decoder_sd
     from ln3diff_amd.nsr.triplane import Triplane, draw_render_noise
