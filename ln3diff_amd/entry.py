@@ -273,7 +273,8 @@ def load_conditioning(args, dev, objaverse=True):
 
 
 def _read_image(path):
-    """[1, 3, H, W] in [-1, 1] from a .npy / .pt array ([H, W, 3] uint8 or [3, H, W] float) or a binary PPM (P6); the preprocessing
+    """[1, 3, H, W] in [-1, 1] from a .npy / .pt array ([H, W, 3] uint8 or [3, H, W] float), a binary PPM (P6) or any image Pillow
+    decodes (alpha composited on white); the preprocessing
     to 224^2 and the CLIP / DINO normalisation happen in the embedders (sgm/image_encoders.py)."""
     if path.endswith('.npy') or path.endswith('.pt'):
         a = torch.as_tensor(np.load(path) if path.endswith('.npy') else torch.load(path))
@@ -288,7 +289,18 @@ def _read_image(path):
             w, h = int(toks[1]), int(toks[2])
             a = torch.frombuffer(bytearray(f.read(w * h * 3)), dtype=torch.uint8).reshape(h, w, 3)
     else:
-        raise SystemExit(f"--image_path {path}: .npy / .pt arrays and binary .ppm are read here (no image codec in this build)")
+        # encoded images (png / jpg / webp ...) through Pillow when the environment has it, as the reference's loaders do
+        # (the released demo reads RGBA pngs and composites them on white: datasets/g_buffer_objaverse.py preprocessing)
+        try:
+            from PIL import Image
+        except ImportError:
+            raise SystemExit(f"--image_path {path}: .npy / .pt arrays and binary .ppm are read without a codec; encoded images need Pillow")
+        im = Image.open(path)
+        if im.mode in ('RGBA', 'LA', 'P'):
+            im = im.convert('RGBA')
+            bg = Image.new('RGBA', im.size, (255, 255, 255, 255))
+            im = Image.alpha_composite(bg, im)
+        a = torch.from_numpy(np.asarray(im.convert('RGB')).copy())
     if a.dtype == torch.uint8:
         a = a.float() / 127.5 - 1.0
     a = a.float()
@@ -305,6 +317,18 @@ def _save_ppm(path, frame):
     f0 = np.clip((frame.transpose(1, 2, 0) + 1) * 127.5, 0, 255).astype(np.uint8)
     with open(path, 'wb') as f:
         f.write(b'P6 %d %d 255\n' % (f0.shape[1], f0.shape[0]) + f0.tobytes())
+
+
+def _save_video(path, frames):
+    """Orbit video of one sample, frames [V, 3, R, R] in [-1, 1] -> animated GIF through Pillow (the reference writes an mp4 with
+    imageio, nsr/train_util_diffusion.py:252; no video encoder exists in this environment).  Returns False without Pillow."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return False
+    ims = [Image.fromarray(np.clip((f.transpose(1, 2, 0) + 1) * 127.5, 0, 255).astype(np.uint8)) for f in frames]
+    ims[0].save(path, save_all=True, append_images=ims[1:], duration=66, loop=0)
+    return True
 
 
 def run(args, objaverse=None):
@@ -412,6 +436,12 @@ def run(args, objaverse=None):
     for j, (smp, view) in enumerate(frames['pair_index'].tolist()):
         if view == 0:
             _save_ppm(os.path.join(args.logdir, f'sample{smp}_view0.ppm'), fr[j])
+    # per-sample orbit video for every sample whose views all sit on this rank (always the case with at least as many samples as ranks)
+    pairs = frames['pair_index'].tolist()
+    for smp in sorted({s_ for s_, _ in pairs}):
+        idx = sorted((view, j) for j, (s_, view) in enumerate(pairs) if s_ == smp)
+        if len(idx) == V and V > 1:
+            _save_video(os.path.join(args.logdir, f'sample{smp}_video.gif'), [fr[j] for _, j in idx])
     if rank == 0:
         np.save(os.path.join(args.logdir, 'latents_all.npy'), lat_all.cpu().numpy())
         print(f"[rank0] {kind}: sampled {Bt} latents ({P} condition(s) x {args.num_samples}) and rendered {Bt * V} views on {world} GPU(s); "
