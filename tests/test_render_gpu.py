@@ -88,3 +88,27 @@ def test_render_256_properties(hip_lib):
         assert float((a['image_raw'] - 1.0).abs()[empty.expand(-1, 3, -1, -1)].max()) < 1e-4
     d = a['image_depth']
     assert float(d.min()) > 0.5 and float(d.max()) < 3.0
+
+
+def test_render_is_bitwise_repeatable_over_scenes(hip_lib):
+    """r4: the rays on which an SLP build of the marcher differs from launch to launch are few and scene-dependent
+    (profiles/r4_render_spill.md), so one scene says little: random planes, several orbits and resolutions, each rendered 4 times by
+    the shipped library - identical bits (tools/render_repeat_sweep.py is the same sweep as a tool)."""
+    from ln3diff_amd.nsr.triplane import Triplane
+    from ln3diff_amd.synth import synth_input, orbit_cameras
+    tp = Triplane(img_resolution=256)
+    tp.decoder.load_state_dict(_decoder_sd(4.0))
+    tp = tp.cuda()
+    for seed, (V, res, el, rad) in enumerate(((8, 256, 40.0, 1.5), (12, 128, -20.0, 2.2), (2, 512, 5.0, 1.7719), (8, 256, 75.0, 1.3))):
+        pcl = tp.to_channel_last(synth_input('planes', (1, 96, 128, 128), 10 + seed, 4.0).cuda())
+        cams = orbit_cameras(V, radius=rad, elevation_deg=el).cuda()
+        g = torch.Generator(device='cuda').manual_seed(seed)
+        j = torch.rand(V, res * res, 64, device='cuda', generator=g)
+        u = torch.rand(V * res * res, 64, device='cuda', generator=g)
+        idx = torch.zeros(V, dtype=torch.int32, device='cuda')
+        f = lambda: tp(c=cams, planes_channel_last=pcl, plane_index=idx, neural_rendering_resolution=res, jitter=j, u_fine=u)
+        ref = f()
+        for _ in range(3):
+            o = f()
+            for k in ('image_raw', 'image_depth', 'weights_samples'):
+                assert torch.equal(ref[k], o[k]), (V, res, el, rad, k)
