@@ -354,6 +354,11 @@ def main():
     ap.add_argument("--ode-method", default="euler", choices=["euler", "heun", "dopri5"],
                     help="i23d workload: euler = configs[2] (50 fixed steps); dopri5 = the released sampler's default (torchdiffeq "
                          "semantics, atol 1e-6, rtol 1e-3: the number of network evaluations is decided by the solver and reported)")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="t23d: sub-batches of the denoise loop on their own HIP streams (EulerEDMSampler lanes; default: the sampler's)")
+    ap.add_argument("--unfolded-steps", type=int, default=2,
+                    help="extra steps after the timed region with the zero-context fold of the unconditional CFG half disabled "
+                         "(prints value_unfolded; 0 = skip)")
     ap.add_argument("--dist", action="store_true",
                     help="go through torch.distributed.run + an RCCL process group even with --gpus 1 (the N-GPU code path on one GPU)")
     args = ap.parse_args()
@@ -421,6 +426,8 @@ def main():
         cond = {'crossattn': c_all[lo:hi].contiguous()}
         uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
         pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
+        if args.lanes is not None:
+            pipe.sampler.lanes = args.lanes
 
         eng = pipe
 
@@ -455,6 +462,28 @@ def main():
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt)
     ok = bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]['image_raw']).all())
+    out_timed = out
+    fc1_events = dit._fc1_probe['events'] if getattr(dit, '_fc1_probe', None) else []      # the timed region's launches only
+    dit._fc1_probe = None
+    # The same step with the unconditional half's cross-attention NOT folded (what a non-zero uc context costs): a few extra steps
+    # after the timed region, timed the same way, so the driver-run record holds both figures.
+    value_unfolded = None
+    if args.unfolded_steps > 0 and not os.environ.get("LN3D_NO_UC_FOLD"):
+        os.environ["LN3D_NO_UC_FOLD"] = "1"
+        one_step()                                           # warm-up of the unfolded shapes (workspaces, tile choice)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.unfolded_steps):
+            one_step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        dtu = parallel.max_over_ranks(time.perf_counter() - t1)
+        del os.environ["LN3D_NO_UC_FOLD"]
+        value_unfolded = round(Bt * args.unfolded_steps / dtu, 5)
+    out = out_timed
 
     if rank == 0:
         if i23d:
@@ -485,8 +514,9 @@ def main():
                        # and is folded (exact algebra, tests/test_dit_gpu.py / test_i23d_gpu.py); LN3D_NO_UC_FOLD=1 gives the unfolded figure
                        "cfg_uncond": ("zero unconditional context (released configuration), " +
                                       ("NOT folded (LN3D_NO_UC_FOLD=1)" if os.environ.get("LN3D_NO_UC_FOLD") else
-                                       "cross-attention of the unconditional half folded; unfolded figure: profiles/r4_bench_%s_nofold.json"
-                                       % ("i23d" if i23d else "t23d")))},
+                                       "cross-attention of the unconditional half folded; value_unfolded = the same step without the fold"))},
+            "value_unfolded": value_unfolded,
+            "lanes": (getattr(getattr(eng, "sampler", None), "lanes", None) or int(os.environ.get("LN3D_LANES", "1") or 1)) if not i23d else 1,
             "finite": ok,
             "ranks_seen": seen, "collectives": parallel.collective_info(), "bcast_ms": round(bcast_ms, 2),
             "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps if (not i23d or args.ode_method == "euler") else -1),
@@ -499,8 +529,7 @@ def main():
                                    "atol": 1e-6, "rtol": 1e-3, "output_grid": "linspace(0, 1, %d)[-1] by 4th-order dense output" % args.sample_steps})
         if not args.no_probes:
             D = dit.embed_dim
-            ev = dit._fc1_probe['events'] if getattr(dit, '_fc1_probe', None) else []
-            dit._fc1_probe = None
+            ev = fc1_events
             rec["roofline"] = roofline_probe(dev, 2 * B, D, tokens=768)
             if ev:
                 us = sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3

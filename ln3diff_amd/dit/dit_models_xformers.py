@@ -208,14 +208,15 @@ def f32(t, device):
 
 
 class Workspace:
-    """Shape-keyed cache of device scratch tensors (allocated once; no allocation in the step loop)."""
+    """Shape-keyed cache of device scratch tensors (allocated once; no allocation in the step loop).  One set per HIP stream:
+    sub-batches that run concurrently on their own streams (sgm.sampling.EulerEDMSampler lanes) must not share activations."""
 
     def __init__(self, device):
         self.device = device
         self._t = {}
 
     def get(self, name, shape, dtype, zero=False):
-        key = (name, tuple(shape), dtype)
+        key = (name, tuple(shape), dtype, torch.cuda.current_stream(self.device).cuda_stream)
         t = self._t.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)

@@ -128,7 +128,8 @@ class T23DPipeline:
 
     @torch.no_grad()
     def sample_latent(self, z, cond, uc=None):
-        return self.sampler(self.denoiser, self.dit, z, cond, _zero_uc(cond) if uc is None else uc)
+        # DiffusionEngineLSGM.sample (:401-404): the sampler gets the closure `(input, sigma, c) -> denoised` over denoiser + model
+        return self.sampler(self.denoiser.bind(self.dit), z, cond, uc=_zero_uc(cond) if uc is None else uc)
 
     # DiffusionEngineLSGM.sample (:386-407): z ~ randn(seed), shape [N, 3*C, S, S]
     @torch.no_grad()

@@ -27,7 +27,7 @@ def smoke():
     cond = {'crossattn': synth_input('c', (1, 77, 768), 41)}
     uc = {'crossattn': torch.zeros(1, 77, 768)}
     y = EulerEDMSampler(num_steps=4, guider=VanillaCFG(6.5))(
-        DiscreteDenoiser(), m, z.to(dev), {k: v.to(dev) for k, v in cond.items()}, {k: v.to(dev) for k, v in uc.items()})
+        DiscreteDenoiser().bind(m), z.to(dev), {k: v.to(dev) for k, v in cond.items()}, {k: v.to(dev) for k, v in uc.items()})
     y_ref = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2), z, cond, uc, 4, 6.5)
     e1 = float((y.cpu() - y_ref).norm() / y_ref.norm())
     # -- render 2 views at 16^2

@@ -50,12 +50,24 @@ class LegacyDDPMDiscretization:
 
 
 class VanillaCFG:
+    """guiders.py:24-42: prepare_inputs doubles the batch as [uc ; c]; __call__ = x_u + scale * (x_c - x_u)."""
+
     def __init__(self, scale):
         self.scale = scale
 
+    def prepare_inputs(self, x, s, c, uc):
+        c_out = {}
+        for k in c:
+            if k in ("vector", "crossattn", "concat"):
+                c_out[k] = torch.cat((uc[k], c[k]), 0)
+            else:
+                assert c[k] == uc[k]
+                c_out[k] = c[k]
+        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+
 
 class DiscreteDenoiser:
-    """EpsScaling + index quantisation; `sigmas` is the ascending 1000-entry table."""
+    """EpsScaling + index quantisation; `sigmas` is the ascending 1000-entry table (denoiser.py:45-78, denoiser_scaling.py:29-37)."""
 
     def __init__(self, num_idx=1000, discretization=None):
         self.discretization = discretization or LegacyDDPMDiscretization()
@@ -70,68 +82,221 @@ class DiscreteDenoiser:
         s = float(self.sigmas[i])
         return s, self.sigma_to_idx(s)
 
+    @torch.no_grad()
+    def __call__(self, network, input, sigma, cond, **additional_model_inputs):
+        """Denoiser.forward (denoiser.py:24-44) with EpsScaling: network(input * c_in, idx(sigma), cond) * (-sigma_q) + input.
+        `network` is a ln3diff_amd DiT (c_in rides on its patch-embed kernel) or any callable (x, t, cond) -> eps on the device.
+        One sigma per call is assumed to be shared by the batch (every sampler of this path), like the table lookup it feeds."""
+        sig, idx = self.quantize(float(sigma.reshape(-1)[0]))
+        c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
+        n = input.shape[0]
+        t = torch.full((n,), float(idx), device=input.device, dtype=torch.float32)
+        if hasattr(network, 'prepare_context'):
+            eps = network(input, t, context=cond, in_scale=torch.full((n,), c_in, device=input.device, dtype=torch.float32),
+                          **additional_model_inputs)
+        else:
+            eps = network(input * c_in, t, cond, **additional_model_inputs)
+        out = torch.empty_like(input, dtype=torch.float32)
+        ops.lincomb(input.contiguous().float(), [eps.contiguous().float()], [-sig], out)       # c_skip = 1, c_out = -sigma
+        return out
+
+    def bind(self, network, **additional_model_inputs):
+        """The closure DiffusionEngineLSGM.sample hands to its sampler (sgm_DiffusionEngine.py:401-403):
+        `lambda input, sigma, c: self.denoiser(self.model, input, sigma, c, **kwargs)` - as an object the sampler can look into."""
+        return BoundDenoiser(self, network, **additional_model_inputs)
+
+
+class BoundDenoiser:
+    def __init__(self, denoiser, network, **additional_model_inputs):
+        self.denoiser, self.network, self.kw = denoiser, network, additional_model_inputs
+
+    def __call__(self, input, sigma, c):
+        return self.denoiser(self.network, input, sigma, c, **self.kw)
+
+
+def _find_pair(denoiser):
+    """(DiscreteDenoiser, ln3diff_amd network) behind the sampler's `denoiser` argument, or (None, None).
+    Recognised: BoundDenoiser; a Python closure whose cells hold the pair directly or an engine object with `.denoiser` and
+    `.model` (the reference's own lambda, sgm_DiffusionEngine.py:401-403).  Anything else runs the generic loop."""
+    if isinstance(denoiser, BoundDenoiser):
+        return (denoiser.denoiser, denoiser.network) if not denoiser.kw and hasattr(denoiser.network, 'prepare_context') else (None, None)
+    den = net = None
+    extra = False
+    for cell in getattr(denoiser, '__closure__', None) or ():
+        try:
+            o = cell.cell_contents
+        except ValueError:
+            continue
+        if isinstance(o, DiscreteDenoiser):
+            den = o
+        elif hasattr(o, 'prepare_context') and callable(o):
+            net = o
+        elif isinstance(getattr(o, 'denoiser', None), DiscreteDenoiser) and hasattr(getattr(o, 'model', None), 'prepare_context'):
+            den, net = o.denoiser, o.model
+        elif isinstance(o, dict) and o:
+            extra = True                                      # **kwargs forwarded to the network: not the plain pair
+    return (den, net) if (den is not None and net is not None and not extra) else (None, None)
+
 
 class EulerEDMSampler:
-    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, use_graph=None, **_):
+    """sampling.py:82-130,211-215.  `lanes`: the batch is split into that many independent sub-batches that run the whole loop
+    on their own HIP streams (their kernels interleave on the device: one lane's HBM-bound epilogues and norms overlap the
+    other's MFMA main loops); None follows LN3D_LANES (default 1).  Results do not depend on it beyond the bf16 tile choice."""
+
+    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, use_graph=None, lanes=None, **_):
         assert s_churn == 0.0, "released config: gamma = 0 (deterministic)"
         self.num_steps = num_steps
         self.use_graph = use_graph            # None: follow LN3D_GRAPH
+        self.lanes = lanes
         self.guider = guider or VanillaCFG(6.5)
         self.discretization = discretization or LegacyDDPMDiscretization()
 
     @torch.no_grad()
-    def __call__(self, denoiser, network, x, cond, uc=None, num_steps=None, trace=None):
-        """x [B,12,32,32] f32 device noise (consumed in place: returns the final latent).
-        network(x, t, context_cache=..., in_scale=...) is a ln3diff_amd DiT; cond/uc dicts with 'crossattn'."""
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None):
+        """The reference's call (sampling.py:109): denoiser = the engine's closure (input, sigma, c) -> denoised; x [B,12,32,32]
+        f32 device noise (consumed in place: returns the final latent); cond / uc dicts with 'crossattn'.
+        Fast path (context K/V, the timestep sub-network of the whole schedule and the CFG + Euler update fused): taken when the
+        closure is recognisably this package's DiscreteDenoiser over one of its networks (`DiscreteDenoiser.bind(network)`, the
+        reference's own lambda over an engine, or `network=` with a DiscreteDenoiser).  Any other callable runs the generic loop
+        with the same arithmetic, one closure call per step."""
+        if network is not None and isinstance(denoiser, DiscreteDenoiser):
+            den, net = denoiser, network
+        else:
+            den, net = _find_pair(denoiser)
+        if net is None:
+            return self._generic(denoiser, x, cond, uc, num_steps, trace)
+        lanes = self.lanes if self.lanes is not None else int(os.environ.get('LN3D_LANES', '1') or 1)
+        B = x.shape[0]
+        uc = cond if uc is None else uc
+        if lanes <= 1 or B < 2 * lanes or trace is not None or x.device.type != 'cuda':
+            return self._fast(den, net, x, cond, uc, num_steps, trace)
+        return self._fast_lanes(den, net, x, cond, uc, num_steps, lanes)
+
+    # ------------------------------------------------------------------ generic: the reference loop, one closure call per step
+    def _generic(self, denoiser, x, cond, uc, num_steps, trace):
         n = self.num_steps if num_steps is None else num_steps
         sigmas = self.discretization(n, device="cpu")
-        B = x.shape[0]
-        dev = x.device
         uc = cond if uc is None else uc
-        ctx = torch.cat((uc['crossattn'], cond['crossattn']), 0).to(dev)      # VanillaCFG: [uc, c]
-        cache = network.prepare_context(ctx)
-        x = x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
-        t_dev = torch.empty(2 * B, device=dev, dtype=torch.float32)
-        s_dev = torch.empty(2 * B, device=dev, dtype=torch.float32)
-        quant = [denoiser.quantize(sigmas[i]) for i in range(n)]
-        mod_all = None
-        if hasattr(network, 'prepare_timesteps') and not os.environ.get('LN3D_NO_MODCACHE'):   # timestep-only sub-network for the whole schedule in one pass
-            t_table = torch.tensor([float(q[1]) for q in quant], dtype=torch.float32)[:, None].expand(n, 2 * B)
-            mod_all = network.prepare_timesteps(t_table)
-        # Optional HIP-graph replay of the network evaluation (LN3D_GRAPH=1 or use_graph=True): the ~220 launches of a forward are
-        # captured once and replayed per step; what changes between steps goes through fixed device buffers (x in place, t_dev,
-        # s_dev, the step's modulation rows copied into mod_step).  The loop is already 99 % kernel-busy without it (DESIGN.md 9).
-        graph, eps_g, mod_step = None, None, None
-        want_graph = self.use_graph if self.use_graph is not None else bool(os.environ.get('LN3D_GRAPH'))
-        if want_graph and mod_all is not None and n > 2:
-            x = x.contiguous()
-            mrows = mod_all['rows']
-            mod_step = {'mod': torch.empty_like(mod_all['mod'][:mrows]), 'rows': mrows}
-            mod_step['mod'].copy_(mod_all['mod'][:mrows])
-            t_dev.fill_(float(quant[0][1]))
-            s_dev.fill_(1.0)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces, kernel attributes
-                network(x, t_dev, context_cache=cache, in_scale=s_dev, mod_cache=(mod_step, 0))
-            torch.cuda.current_stream(dev).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eps_g = network(x, t_dev, context_cache=cache, in_scale=s_dev, mod_cache=(mod_step, 0))
+        x = (x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))).contiguous()
+        B = x.shape[0]
+        s_in = x.new_ones([B])
+        sc = float(self.guider.scale)
         for i in range(n):
-            sig, idx = quant[i]
-            c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
-            t_dev.fill_(float(idx))
-            s_dev.fill_(c_in)
-            if graph is not None:
-                mod_step['mod'].copy_(mod_all['mod'][i * mrows:(i + 1) * mrows])
-                graph.replay()
-                eps2 = eps_g
-            elif mod_all is not None:
-                eps2 = network(x, t_dev, context_cache=cache, in_scale=s_dev, mod_cache=(mod_all, i))
-            else:
-                eps2 = network(x, t_dev, context_cache=cache, in_scale=s_dev)
-            ops.edm_euler_step(x, eps2, sig, float(sigmas[i + 1]), float(self.guider.scale))
+            sig, nxt = float(sigmas[i]), float(sigmas[i + 1])
+            den = denoiser(*self.guider.prepare_inputs(x, s_in * sig, cond, uc)).contiguous().float()
+            # guider + to_d + euler_step in one combination: x + dt/sigma * (x - (x_u + s (x_c - x_u)))
+            r = (nxt - sig) / sig
+            ops.lincomb(x, [x, den[:B], den[B:]], [r, -r * (1.0 - sc), -r * sc], x)
             if trace is not None:
                 trace.append(x.clone())
         return x
+
+    # ------------------------------------------------------------------ fast path pieces
+    def _prepare(self, den, network, x, cond, uc, n):
+        sigmas = self.discretization(n, device="cpu")
+        B, dev = x.shape[0], x.device
+        ctx = torch.cat((uc['crossattn'], cond['crossattn']), 0).to(dev)      # VanillaCFG: [uc, c]
+        st = {'cache': network.prepare_context(ctx), 'sigmas': sigmas, 'B': B,
+              't_dev': torch.empty(2 * B, device=dev, dtype=torch.float32), 's_dev': torch.empty(2 * B, device=dev, dtype=torch.float32),
+              'quant': [den.quantize(sigmas[i]) for i in range(n)]}
+        st['x'] = x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
+        return st
+
+    def _mod_all(self, network, quant, n, B):
+        if not hasattr(network, 'prepare_timesteps'):
+            return None
+        # timestep-only sub-network for the whole schedule in one pass
+        t_table = torch.tensor([float(q[1]) for q in quant], dtype=torch.float32)[:, None].expand(n, 2 * B)
+        return network.prepare_timesteps(t_table)
+
+    def _step(self, network, st, i, mod_all):
+        sig, idx = st['quant'][i]
+        c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
+        st['t_dev'].fill_(float(idx))
+        st['s_dev'].fill_(c_in)
+        g = st.get('graph')
+        if g is not None:
+            g['mod_step']['mod'].copy_(mod_all['mod'][i * g['mrows']:(i + 1) * g['mrows']])
+            g['graph'].replay()
+            eps2 = g['eps']
+        elif mod_all is not None:
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i))
+        else:
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'])
+        ops.edm_euler_step(st['x'], eps2, sig, float(st['sigmas'][i + 1]), float(self.guider.scale))
+
+    def _capture(self, network, st, mod_all, dev):
+        """Optional HIP-graph replay of the network evaluation (LN3D_GRAPH=1 or use_graph=True): the ~220 launches of a forward
+        are captured once and replayed per step; what changes between steps goes through fixed device buffers (x in place,
+        t_dev, s_dev, the step's modulation rows copied into mod_step)."""
+        st['x'] = st['x'].contiguous()
+        mrows = mod_all['rows']
+        mod_step = {'mod': torch.empty_like(mod_all['mod'][:mrows]), 'rows': mrows}
+        mod_step['mod'].copy_(mod_all['mod'][:mrows])
+        st['t_dev'].fill_(float(st['quant'][0][1]))
+        st['s_dev'].fill_(1.0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces, kernel attributes
+            network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0))
+        st['graph'] = {'graph': graph, 'eps': eps_g, 'mod_step': mod_step, 'mrows': mrows}
+
+    def _fast(self, den, network, x, cond, uc, num_steps, trace):
+        n = self.num_steps if num_steps is None else num_steps
+        st = self._prepare(den, network, x, cond, uc, n)
+        mod_all = self._mod_all(network, st['quant'], n, st['B'])
+        want_graph = self.use_graph if self.use_graph is not None else bool(os.environ.get('LN3D_GRAPH'))
+        if want_graph and mod_all is not None and n > 2:
+            self._capture(network, st, mod_all, x.device)
+        for i in range(n):
+            self._step(network, st, i, mod_all)
+            if trace is not None:
+                trace.append(st['x'].clone())
+        return st['x']
+
+    def _fast_lanes(self, den, network, x, cond, uc, num_steps, lanes):
+        """`lanes` sub-batches, each the complete EulerEDM loop of its samples on its own stream.  The network keeps one workspace
+        per stream (dit_models_xformers.Workspace), the schedule's modulation rows are shared (read-only)."""
+        n = self.num_steps if num_steps is None else num_steps
+        dev = x.device
+        B = x.shape[0]
+        cur = torch.cuda.current_stream(dev)
+        bounds = [B * k // lanes for k in range(lanes + 1)]
+        sl = lambda d, a, b: {k: v[a:b] for k, v in d.items()}
+        streams = _lane_streams(dev, lanes)
+        # every sample of a step shares its timestep, so one table serves lanes of any size (rows == 1); otherwise per lane
+        sig_all = self.discretization(n, device="cpu")
+        mod_shared = self._mod_all(network, [den.quantize(sig_all[i]) for i in range(n)], n, bounds[1] - bounds[0])
+        shared_ok = mod_shared is None or mod_shared['rows'] == 1
+        sts = []
+        for k in range(lanes):
+            a, b = bounds[k], bounds[k + 1]
+            streams[k].wait_stream(cur)
+            with torch.cuda.stream(streams[k]):
+                st = self._prepare(den, network, x[a:b], sl(cond, a, b), sl(uc, a, b), n)
+                st['mod'] = mod_shared if shared_ok else self._mod_all(network, st['quant'], n, b - a)
+                sts.append(st)
+        for i in range(n):
+            for k in range(lanes):
+                with torch.cuda.stream(streams[k]):
+                    self._step(network, sts[k], i, sts[k]['mod'])
+        out = torch.empty_like(x, dtype=torch.float32)
+        for k in range(lanes):
+            with torch.cuda.stream(streams[k]):
+                out[bounds[k]:bounds[k + 1]].copy_(sts[k]['x'])
+            cur.wait_stream(streams[k])
+        return out
+
+
+_LANE_STREAMS = {}
+
+
+def _lane_streams(dev, n):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _LANE_STREAMS[key]

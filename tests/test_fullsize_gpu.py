@@ -38,7 +38,7 @@ def test_full_edm_ditl2_250_vs_reference_golden(hip_lib):
     cond = {'crossattn': synth_input('c', (1, 77, 768), 41).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
     tr = []
-    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z, cond, uc, trace=tr)
+    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z, cond, uc, trace=tr)
     errs = {k: rel_l2(t.cpu(), g[k]) for k, t in (('first', tr[0]), ('s50', tr[50]), ('s125', tr[125]), ('s200', tr[200]), ('final', y))}
     print('full EDM-250 DiT-L/2:', errs)
     assert torch.isfinite(y).all()

@@ -38,7 +38,7 @@ def test_t23d_bench_geometry_b8_vs_reference_goldens(hip_lib):
     cond = {'crossattn': torch.cat([synth_input('c', (1, 77, 768), s) for s in seeds]).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
     tr = []
-    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z.clone(), cond, uc, trace=tr)
+    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z.clone(), cond, uc, trace=tr)
     assert torch.isfinite(y).all()
     # (a) the first step of every sample of the batch vs the reference's B = 1 step of that sample
     e1 = [rel_l2(tr[0][i].cpu(), g1['x1'][i]) for i in range(8)]
@@ -50,7 +50,7 @@ def test_t23d_bench_geometry_b8_vs_reference_goldens(hip_lib):
     assert errs['first'] < 1e-3 and max(errs.values()) < 1e-2, errs
     # (c) a sample in the middle of the batch (rows 3 x 768 .., the uncond / cond halves 8 samples apart) vs its own B = 1 run
     tr1 = []
-    y1 = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z[3:4].clone(), {'crossattn': cond['crossattn'][3:4]},
+    y1 = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z[3:4].clone(), {'crossattn': cond['crossattn'][3:4]},
                                                                {'crossattn': uc['crossattn'][3:4]}, trace=tr1)
     e_b = {'first': rel_l2(tr[0][3], tr1[0][0]), 's125': rel_l2(tr[125][3], tr1[125][0]), 'final': rel_l2(y[3], y1[0])}
     print('sample 3: batched vs B=1 on the HIP path:', e_b)
@@ -66,7 +66,7 @@ def test_t23d_bench_geometry_is_bitwise_reproducible(hip_lib):
     z = synth_input('z', (8, 12, 32, 32), 77).cuda()
     cond = {'crossattn': synth_input('c', (8, 77, 768), 77).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
-    run = lambda: EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z.clone(), cond, uc)
+    run = lambda: EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z.clone(), cond, uc)
     a, b = run(), run()
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
@@ -111,14 +111,14 @@ def test_xl2_edm10_vs_reference_golden(hip_lib):
     cond = {'crossattn': synth_input('c', (1, 77, 768), 43).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
     tr = []
-    y = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z, cond, uc, trace=tr)
+    y = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z, cond, uc, trace=tr)
     errs = {'first': rel_l2(tr[0].cpu(), g['first']), 's5': rel_l2(tr[5].cpu(), g['s5']), 'final': rel_l2(y.cpu(), g['final'])}
     print('DiT-XL/2 EulerEDM-10:', errs)
     assert errs['first'] < 5e-3 and max(errs.values()) < 1e-2, errs      # measured 1.9e-3 / 2.2e-3 / 2.2e-3 (one XL/2 forward: 1.4e-3, r2)
     # the same at configs[3]'s per-GPU batch (8 samples, network batch 16): sample 0 unchanged by its neighbours
     zb = torch.cat([synth_input('z', (1, 12, 32, 32), 43 + i) for i in range(8)]).cuda()
     cb = {'crossattn': torch.cat([synth_input('c', (1, 77, 768), 43 + i) for i in range(8)]).cuda()}
-    yb = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, zb, cb, {'crossattn': torch.zeros_like(cb['crossattn'])})
+    yb = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), zb, cb, {'crossattn': torch.zeros_like(cb['crossattn'])})
     e8 = rel_l2(yb[0].cpu(), g['final'][0])
     print('DiT-XL/2 B=8 sample 0 final:', e8)
     assert e8 < 1e-2, e8
@@ -134,7 +134,7 @@ def test_xl2_edm250_vs_reference_golden(hip_lib):
     z = synth_input('z', (1, 12, 32, 32), 41).cuda()
     cond = {'crossattn': synth_input('c', (1, 77, 768), 41).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
-    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser(), m, z, cond, uc)
+    y = EulerEDMSampler(num_steps=250, guider=VanillaCFG(6.5))(DiscreteDenoiser().bind(m), z, cond, uc)
     e = rel_l2(y.cpu(), g['final'])
     print('DiT-XL/2 EulerEDM-250 final latent:', e)
     assert e < 1e-2, e

@@ -34,7 +34,7 @@ def test_edm_euler_cfg_vs_reference_golden(hip_lib, steps):
     den = DiscreteDenoiser()
     assert den.quantize(sampler.discretization(steps)[0])[1] == int(g['idx_first'][0])
     tr = []
-    y = sampler(den, m, z, cond, uc, trace=tr)
+    y = sampler(den.bind(m), z, cond, uc, trace=tr)
     e0, em, e1 = rel_l2(tr[0].cpu(), g['first']), rel_l2(tr[steps // 2].cpu(), g['mid']), rel_l2(y.cpu(), g['final'])
     print('edm', steps, 'first', e0, 'mid', em, 'final', e1)
     assert e0 < 2e-3 and e1 < 1e-2, (e0, em, e1)
@@ -121,6 +121,6 @@ def test_edm_graph_replay_is_bitwise_identical(hip_lib):
     z = synth_input('z', (2, 12, 32, 32), 41).cuda()
     cond = {'crossattn': synth_input('c', (2, 77, 768), 41).cuda()}
     uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
-    ya = EulerEDMSampler(num_steps=12, guider=VanillaCFG(6.5), use_graph=False)(DiscreteDenoiser(), m, z.clone(), cond, uc)
-    yb = EulerEDMSampler(num_steps=12, guider=VanillaCFG(6.5), use_graph=True)(DiscreteDenoiser(), m, z.clone(), cond, uc)
+    ya = EulerEDMSampler(num_steps=12, guider=VanillaCFG(6.5), use_graph=False)(DiscreteDenoiser().bind(m), z.clone(), cond, uc)
+    yb = EulerEDMSampler(num_steps=12, guider=VanillaCFG(6.5), use_graph=True)(DiscreteDenoiser().bind(m), z.clone(), cond, uc)
     assert torch.isfinite(yb).all() and torch.equal(ya, yb)
