@@ -379,7 +379,7 @@ def main():
                          "what ran" % (args.gpus, env_world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    rank, local_rank, world = parallel.setup_dist()
+    rank, local_rank, world = parallel.setup_dist(timeout_s=parallel.BENCH_PG_TIMEOUT_S)   # no rank-0-only phase here: fail fast
     assert world == args.gpus
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)

@@ -29,6 +29,16 @@ int ln3d_abi_version(void);
  * process, at the first launch that consults them.  A harness that changes them afterwards calls this to have them re-read. */
 void ln3d_reload_env(void);
 
+/* ---------------------------------------------------------------- streams that own part of the chip (ABI 9)
+ * The reference runs its sampling loop on ONE CUDA stream (torch's current stream; nsr/lsgm/sgm_DiffusionEngine.py:386-407).
+ * Here independent sub-batches of that loop ("lanes") may run on streams restricted to disjoint sets of compute units:
+ * mask bit i = XCD (i % 8), CU (i / 8) of that XCD (hipExtStreamCreateWithCUMask); `words` 32-bit words.  The tile selection of
+ * the kernels launched on such a stream counts the mask's compute units instead of the device's.  The stream lives for the
+ * process (at most 32 of them). */
+int ln3d_device_cus(void);
+int ln3d_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
+int ln3d_stream_cu_count(void* stream);
+
 /* ---------------------------------------------------------------- GEMM with fused epilogues
  * out[m, n] = epilogue( sum_k X[m,k] * W[n,k] + bias[n] ),  X:[M,K] bf16 (tokens), W:[N,K] bf16
  * (torch.nn.Linear weight layout).  fp32 accumulation on MFMA 32x32x16 bf16.  K % 64 == 0, N % 4 == 0.

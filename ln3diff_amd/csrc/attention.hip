@@ -1292,17 +1292,6 @@ static int launch_attn(const AttnP& p, hipStream_t s) {
   return ln3d_check_launch();
 }
 
-static int num_cus_attn() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
-
 static int launch_attn_stream(AttnP p, hipStream_t s) {
   constexpr int LDS = 8 * 16384 + 8 * 4096;     // all 160 KiB of the CU: one workgroup per CU
   static AttrOnce attr_once;
@@ -1311,7 +1300,7 @@ static int launch_attn_stream(AttnP p, hipStream_t s) {
   }
   // one workgroup per (batch, head) walks all its query blocks; with fewer heads than CUs the query blocks of a head are
   // shared out so that every CU has work
-  const int nqb = (p.Nq + 255) / 256, BH = p.B * p.H, cus = num_cus_attn();
+  const int nqb = (p.Nq + 255) / 256, BH = p.B * p.H, cus = ln3d_stream_cus(s);
   int nsplit = 1;
   if (BH < cus) { nsplit = (cus + BH - 1) / BH; if (nsplit > nqb) nsplit = nqb; }
   if (attn_cfg().split > 0) { nsplit = attn_cfg().split; if (nsplit > nqb) nsplit = nqb; }
@@ -1363,7 +1352,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
     if ((a->Nk & 255) == 0 && a->Nk_pad == a->Nk && cfg.ver != 2) {
       // K-resident kernel: K of a head fits beside the V^T ring (Nk <= 768) and there is a head for every CU, so that one
       // workgroup per head walks all its query blocks (fewer heads: the query blocks of a head are shared out - attn_stream)
-      if (cfg.ver != 3 && a->Nk >= 512 && a->Nk <= 768 && (a->Nq & 255) == 0 && a->Nq_pad == a->Nq && p.B * p.H >= num_cus_attn())
+      if (cfg.ver != 3 && a->Nk >= 512 && a->Nk <= 768 && (a->Nq & 255) == 0 && a->Nq_pad == a->Nq && p.B * p.H >= ln3d_stream_cus(s))
         return launch_attn_kres(p, s);
       return launch_attn_stream(p, s);
     }

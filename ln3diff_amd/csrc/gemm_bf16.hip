@@ -576,17 +576,6 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
   }
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
-
 
 #ifndef LN3D_RING_D1
 #define LN3D_RING_D1 0       // DMA pieces of a stage issued right behind the barrier (0 = half of them); the rest in the next two substeps
@@ -1193,12 +1182,12 @@ static int forced_cfg() {
   return g_gemm_forced;
 }
 extern "C" void ln3d_gemm_reload_env(void) { g_gemm_forced = -2; }
-static int pick_cfg(int M, int N, bool head_aligned = false) {
+static int pick_cfg(int M, int N, bool head_aligned = false, hipStream_t s = nullptr) {
   if (forced_cfg() >= 0) return forced_cfg();
   if (!(M >= 1536 && N >= 128)) return 0;
   static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
                                                                {8, 128, 384, 0.945f}};
-  const int cus = num_cus();
+  const int cus = ln3d_stream_cus(s);          // a lane stream owns part of the chip (csrc/runtime.hip)
   int best = 8; float best_cost = 1e30f; int64_t best_tiles = 0;
   for (int i = 0; i < 4; ++i) {
     // head split with 64-wide heads: only the configurations whose wave row is ONE head (64 features, NI = 2) have the
@@ -1282,7 +1271,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   const bool head_staged = a->epilogue == LN3D_EPI_HEADS && a->head_dim > 0 && (a->head_dim & 7) == 0 && a->heads > 0 &&
                            ((a->heads * a->head_dim) & 63) == 0 && a->tokens > 0 && (a->tokens & 31) == 0 && (a->M % a->tokens) == 0 &&
                            (a->N % 64) == 0;
-  const int cfg = pick_cfg(a->M, a->N, head_staged);
+  const int cfg = pick_cfg(a->M, a->N, head_staged, s);
   if (p.st_in || p.cs || p.st_out) {
     int fc = cfg == 12 || cfg == 8 ? 9 : cfg;                          // the fused variants exist for the 256x256 / 256x192 / 128x192 tiles
     static const int BFT[15][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {256, 256}, {128, 384}, {256, 192}, {0, 0}, {0, 0}, {384, 192}, {0, 0}, {128, 192}};
@@ -1313,7 +1302,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
           (a->ctx_pad % 64) != 0 || (a->N % 256) != 0)
         return LN3D_ERR_BAD_ARG;
       // 256x192 tiles (8 waves); when they would leave half the chip idle, 128x192 tiles with 4 waves (2 heads per tile)
-      return run_cfg<LN3D_EPI_CROSS_ATTN>(p, s, ((int64_t)(a->N / 256) * ((a->M + 191) / 192) * 2 <= num_cus() && forced_cfg() != 9) ? 14 : 9);
+      return run_cfg<LN3D_EPI_CROSS_ATTN>(p, s, ((int64_t)(a->N / 256) * ((a->M + 191) / 192) * 2 <= ln3d_stream_cus(s) && forced_cfg() != 9) ? 14 : 9);
     case LN3D_EPI_GATE_RES: return run_cfg<LN3D_EPI_GATE_RES>(p, s, cfg);
     case LN3D_EPI_F32_SILU:
       if (!a->out1) return LN3D_ERR_BAD_ARG;

@@ -277,9 +277,32 @@ def plucker_rays(c, S):
     _chk_dev(c)
     V = c.shape[0]
     out = torch.empty(V, 6, S, S, device=c.device, dtype=torch.float32)
-    L.check(L.lib().ln3d_plucker_rays(_p(c.contiguous().float()), _p(out), V, S, _stream()), "plucker_rays")
+    c32 = c.contiguous().float()                     # kept alive across the launch (a temporary's block could be handed out again)
+    L.check(L.lib().ln3d_plucker_rays(_p(c32), _p(out), V, S, _stream()), "plucker_rays")
     return out
 
 
 def vit_assemble(patch, cls, reg, pos, x, B, Lp, R, D):
     L.check(L.lib().ln3d_vit_assemble(_p(patch), _p(cls), _p(reg), _p(pos), _p(x), B, Lp, R, D, _stream()), "vit_assemble")
+
+
+def device_cus():
+    return int(L.lib().ln3d_device_cus())
+
+
+def masked_stream(bits, device):
+    """A HIP stream restricted to the compute units whose mask bits are set (include/ln3d.h: bit i = XCD i % 8, CU i // 8), as a
+    torch stream object.  The stream lives for the process."""
+    nw = (max(bits) // 32) + 1
+    words = [0] * nw
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    arr = (C.c_uint32 * nw)(*words)
+    out = C.c_void_p()
+    with torch.cuda.device(device):
+        L.check(L.lib().ln3d_stream_create_cu_mask(arr, nw, C.byref(out)), "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def stream_cu_count(stream=None):
+    return int(L.lib().ln3d_stream_cu_count(C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)))

@@ -20,8 +20,13 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-PG_TIMEOUT_S = 120      # the sampling path has no long collective: a rank that died must surface as an error within minutes
-                        # (the reference waits 15 h: guided_diffusion/dist_util.py:68)
+# Process-group timeout.  The entry points have rank-0-only phases (conditioner checkpoint load + encoding, then broadcast_object)
+# and unbalanced tails (a rank with a smaller shard waits in all_gather / agree_ok for the others' sampling, dopri5 or mesh
+# export), so the default is generous: 30 min, LN3D_PG_TIMEOUT_S overrides it (the reference waits 15 h:
+# guided_diffusion/dist_util.py:68).  bench.py and the tests, which have no such phase, pass their own short timeout so that a
+# rank that died surfaces within minutes.
+PG_TIMEOUT_S = int(os.environ.get("LN3D_PG_TIMEOUT_S", "1800"))
+BENCH_PG_TIMEOUT_S = 180
 
 
 def launched_by_torchrun():
@@ -31,7 +36,7 @@ def launched_by_torchrun():
 def setup_dist(backend=None, timeout_s=None):
     """env:// rendezvous (reference guided_diffusion/dist_util.py:57-73).  The process group is created whenever the process was
     started by a launcher (RANK / WORLD_SIZE / MASTER_ADDR set) - also with ONE rank, so that a single-GPU box exercises the same
-    RCCL initialisation, broadcast, all_gather and all_reduce calls as an 8-GPU node - and with a short timeout."""
+    RCCL initialisation, broadcast, all_gather and all_reduce calls as an 8-GPU node.  timeout_s: see PG_TIMEOUT_S."""
     import datetime
     rank, local_rank, world = env_rank()
     if (world > 1 or launched_by_torchrun()) and not dist.is_initialized():

@@ -295,8 +295,18 @@ class EulerEDMSampler:
 _LANE_STREAMS = {}
 
 
-def _lane_streams(dev, n):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+def _lane_streams(dev, n, mask=None):
+    """The lanes' streams, created once per (device, count, mode).  mask (None: LN3D_LANE_MASK, default 'cu'):
+      'cu'   lane k owns every n-th CU of EVERY XCD (the GEMMs' XCD-aware tile walk keeps its meaning; weights are shared in each L2)
+      'xcd'  lane k owns whole XCDs (8 / n of them: private L2s)
+      'none' plain streams: the hardware dispatcher interleaves the lanes' workgroups over all CUs."""
+    mask = (mask or os.environ.get('LN3D_LANE_MASK') or 'cu').lower()
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n, mask)
     if key not in _LANE_STREAMS:
-        _LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        if mask == 'none':
+            _LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        else:
+            cus = ops.device_cus()
+            own = (lambda i, k: (i // 8) % n == k) if mask == 'cu' else (lambda i, k: (i % 8) * n // 8 == k)
+            _LANE_STREAMS[key] = [ops.masked_stream([i for i in range(cus) if own(i, k)], dev) for k in range(n)]
     return _LANE_STREAMS[key]

@@ -46,8 +46,9 @@ NULL_CALLS = {
     'ln3d_mesh_emit': (N, 8, F(1), N, N, N, N),
     'ln3d_groupnorm_swish': (N, N, N, N, N, 1, 64, 64, 32, F(1e-6), 1, N),
     'ln3d_im2col3x3': (N, N, 1, 8, 8, 64, 1, 576, N),
+    'ln3d_stream_create_cu_mask': (N, 1, N),
 }
-NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_gemm_norm_fusable'}      # pure host queries
+NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_gemm_norm_fusable', 'ln3d_device_cus', 'ln3d_stream_cu_count'}      # pure host queries
 
 
 def test_every_entry_point_rejects_missing_buffers(hip_lib):
@@ -61,7 +62,7 @@ def test_every_entry_point_rejects_missing_buffers(hip_lib):
 
 
 def test_host_queries(hip_lib):
-    assert hip_lib.ln3d_abi_version() == 8
+    assert hip_lib.ln3d_abi_version() == 9
     # the fused qk-norm epilogue needs head-aligned tiles: 64-wide heads yes, 72-in-128 padded heads no
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3072, 768, 64, 64) == 1
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3 * 16 * 128, 768, 72, 128) == 0
