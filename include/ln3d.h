@@ -296,10 +296,28 @@ typedef struct {
    * call (the video drivers render one camera per call, nsr/train_util_diffusion.py:262-283).  At most
    * (LN3D_RENDER_SCRATCH_FLOATS - 2400) / 8 calls per launch. */
   int views_per_call;
+  /* ---- ABI 9.  All zero = the behaviour of ABI 8 (Objaverse preset, res x res rays per view). */
+  int rays_per_view;     /* M of an explicit ray list [V, M, 3] (any M >= 1, the seam's [N, M, 3] rays are not an image); 0 = res * res.
+                          * rgb is written as [V, 3, M], depth / wsum / visibility as [V, M] */
+  float* visibility;     /* optional [V, M]: T behind the last interval - 'visibility' of ImportanceRenderer.forward's dict (renderer.py:281,
+                          * ray_marcher.py:44) */
+  /* rendering presets of nsr/script_util.py:433-1000 other than Objaverse 64 + 64 'auto' (served by render_generic_kernel): */
+  int depth_resolution, depth_resolution_importance;   /* samples per ray of the two passes, each <= 128 (presets: 48, 64, 80, 96, 128); 0 = 64.
+                                                         * jitter is [V, M, depth_resolution], u_fine [V * M, depth_resolution_importance] and the
+                                                         * optional sampling-detail outputs follow the same counts */
+  int ray_mode;          /* 0: ray_start = ray_end = 'auto' (ray / AABB limits, renderer.py:145-156); 1: the numbers below (renderer.py:157-163,
+                          * ShapeNet / FFHQ presets) */
+  float ray_start, ray_end;
+  int no_bbox_filter;    /* 1: rendering_options without 'filter_out_of_bbox' (renderer.py:343-352: plain _run_model) */
+  /* return_meta outputs (renderer.py:283-300), all optional: the merged, depth-sorted per-sample tensors */
+  float* weights;        /* [V, M, S + NI - 1]   'weights'        */
+  float* all_coords;     /* [V, M, S + NI, 3]    'all_coords'     */
+  float* feature_volume; /* [V, M, S + NI, 3]    'feature_volume' (the sorted colours) */
 } ln3d_render_args;
 /* Triplane.forward -> ImportanceRenderer.forward -> MipRayMarcher2 (nsr/triplane.py:505-750,
- * nsr/volumetric_rendering/renderer.py:133-307, ray_marcher.py:26-68, ray_sampler.py:262-331),
- * depth_resolution = depth_resolution_importance = 64 (Objaverse preset nsr/script_util.py:761-798). */
+ * nsr/volumetric_rendering/renderer.py:133-307, ray_marcher.py:26-68, ray_sampler.py:262-331).  The Objaverse preset
+ * (depth_resolution = depth_resolution_importance = 64, 'auto' limits, bbox filter: nsr/script_util.py:761-798) runs the
+ * lane = sample kernel; the other presets and the return_meta outputs the generic one (same gather + MFMA decoder). */
 int ln3d_render_triplane(const ln3d_render_args* a, void* stream);
 
 /* triplane_decode_grid / forward_points (vit/vit_triplane.py:2009-2112): points f32 [P,3] -> sigma[P], rgb[P,3].

@@ -57,7 +57,10 @@ class RenderArgs(C.Structure):
                 ("jitter", vp), ("u_fine", vp), ("box_warp", f32), ("bbox_min", f32), ("bbox_max", f32),
                 ("white_back", i32), ("rgb", vp), ("depth", vp), ("wsum", vp), ("ray_limits", vp),
                 ("scalars", vp), ("coarse_sigma", vp), ("fine_depths", vp), ("ray_o", vp), ("ray_d", vp),
-                ("fine_sigma", vp), ("coarse_coords", vp), ("fine_coords", vp), ("views_per_call", i32)]
+                ("fine_sigma", vp), ("coarse_coords", vp), ("fine_coords", vp), ("views_per_call", i32),
+                ("rays_per_view", i32), ("visibility", vp), ("depth_resolution", i32), ("depth_resolution_importance", i32),
+                ("ray_mode", i32), ("ray_start", f32), ("ray_end", f32), ("no_bbox_filter", i32),
+                ("weights", vp), ("all_coords", vp), ("feature_volume", vp)]
 
 
 _lib = None

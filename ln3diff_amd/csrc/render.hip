@@ -86,6 +86,12 @@ struct RenderP {
   float* coarse_sigma; float* fine_depths;
   const float* ray_o; const float* ray_d;          // optional explicit rays [V, M, 3] (ImportanceRenderer.forward seam)
   float* fine_sigma; float* coarse_coords; float* fine_coords;
+  int M;                                           // rays per view (res * res, or the length of an explicit ray list)
+  float* vis;                                      // optional [V, M]: transmittance behind the last interval (ray_marcher.py:44)
+  // ---- generic kernel only (render_generic_kernel): the presets other than Objaverse 64 + 64 'auto', and the return_meta outputs
+  int S, NI;                                       // coarse / importance samples per ray (<= 128 each)
+  int numeric; float t_start, t_end;               // ray_start / ray_end given as numbers (renderer.py:157-163) instead of 'auto'
+  float* w_all; float* coords_all; float* colors_all;   // optional [V,M,S+NI-1], [V,M,S+NI,3], [V,M,S+NI,3] (renderer.py:283-300)
 };
 
 // ------------------------------------------------------------------ ray generation + AABB limits
@@ -169,7 +175,7 @@ __global__ void render_init_kernel(uint32_t* scal_u, int groups, float* dec, con
 }
 
 __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_half) {
-  const int M = p.res * p.res;
+  const int M = p.M;
   const int64_t nr = (int64_t)p.V * M;
   const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float tmn = 3.0e38f, tmx = -3.0e38f; int any = 0, grp = -1;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(64 * RENDER_WPB, RENDER_OCC) void render_kernel(Ren
   const char* cimg = stage_decoder(reinterpret_cast<char*>(lds), p.dec, RENDER_WPB);
   float* feat = lds + wid * WAVE_LDS_FLOATS;       // 2048 floats; reused for cdf/bins/merge arrays between shading passes
   char* wl = reinterpret_cast<char*>(feat);
-  const int M = p.res * p.res;
+  const int M = p.M;
   const int64_t nrays = (int64_t)p.V * M;
   const int64_t nwaves = (int64_t)gridDim.x * RENDER_WPB;
   float dmin_l = 3.0e38f, dmax_l = -3.0e38f;
@@ -647,6 +653,10 @@ __global__ __launch_bounds__(64 * RENDER_WPB, RENDER_OCC) void render_kernel(Ren
       p.depth[ray] = acc_d;          // clamped by render_finalize_kernel
       p.wsum[ray] = acc_w;
     }
+    if (p.vis) {                     // T behind the last of the 127 intervals (lane 63: f1 = 1) - 'visibility' of the reference's return dict
+      const float tv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ts * f0 * f1), 63));
+      if (lane == 0) p.vis[ray] = tv;
+    }
   }
   flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
 }
@@ -662,18 +672,285 @@ __global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int
   depth[i] = fminf(fmaxf(dv, lo), hi);
 }
 
+// ------------------------------------------------------------------ generic ray-marcher: every preset of nsr/script_util.py:433-1000
+// render_kernel above is the Objaverse preset (64 + 64 samples, 'auto' limits, bbox filter) with lane = sample.  The other presets the
+// reference's entry points select - depth_resolution / depth_resolution_importance in {48, 64, 80, 96, 128}, numeric ray_start /
+// ray_end (ShapeNet, FFHQ), no bbox filter - and the per-sample outputs of return_meta (weights, all_coords, feature_volume:
+// renderer.py:283-300) go through this kernel: still one wavefront per ray and the same gather + MFMA decoder (shade64, up to two
+// passes of 64 points per sampling stage), but the per-ray arrays live in the wave's LDS (20 KB) and a lane owns CONSECUTIVE
+// intervals of the march (2 of the <= 127 coarse ones, 4 of the <= 255 merged ones), so any sample count <= 128 + 128 fits one code
+// path.  Evaluation order follows the reference operator by operator like the kernel above; it is not tuned beyond that.
+#define GEN_MAXS 128
+#define G_ZC 2048               // float offsets inside the wave's region: [0, 2048) is shade64's feature tile
+#define G_ZF (G_ZC + 5 * GEN_MAXS)
+#define G_SRT (G_ZF + 5 * GEN_MAXS)
+#define G_W (G_SRT + 5 * 2 * GEN_MAXS)
+#define G_CDF (G_W + 2 * GEN_MAXS)
+#define G_BIN (G_CDF + GEN_MAXS)
+#define GEN_WAVE_FLOATS (G_BIN + GEN_MAXS)
+#define GEN_LDS_BYTES (4 * GEN_WAVE_FLOATS * 4 + DEC_BYTES)
+static_assert(GEN_LDS_BYTES <= 160 * 1024, "one workgroup of the generic ray-marcher per CU");
+
+// MipRayMarcher2.run_forward over n samples held as 5 planes {z, sigma, r, g, b} with plane stride PS in LDS: lane owns intervals
+// IPL * lane .. IPL * lane + IPL - 1.  Returns the five sums (same value in every lane) and T behind the last interval; writes the
+// n - 1 weights to w_lds (LDS, may be null) and w_glb (global, may be null).
+template <int IPL>
+__device__ __forceinline__ void march_lds(const float* a, int PS, int n, int lane, float* w_lds, float* w_glb, float& acc_r, float& acc_g,
+                                          float& acc_b, float& acc_d, float& acc_w, float& vis) {
+  float al[IPL], fk[IPL], mr[IPL], mg[IPL], mb[IPL], mz[IPL];
+  float prod = 1.0f;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int i = IPL * lane + q;
+    const bool ok = i < n - 1;
+    const int i0 = ok ? i : n - 1, i1 = ok ? i + 1 : n - 1;
+    const float z0 = a[i0], z1 = a[i1], s0 = a[PS + i0], s1 = a[PS + i1];
+    const float dm = softplus20_hw((s0 + s1) * 0.5f - 1.0f);
+    const float alpha = ok ? 1.0f - exp_neg_hw(dm * (z1 - z0)) : 0.f;
+    al[q] = alpha;
+    fk[q] = ok ? (1.0f - alpha + 1e-10f) : 1.0f;
+    prod *= fk[q];
+    mr[q] = (a[2 * PS + i0] + a[2 * PS + i1]) * 0.5f; mg[q] = (a[3 * PS + i0] + a[3 * PS + i1]) * 0.5f;
+    mb[q] = (a[4 * PS + i0] + a[4 * PS + i1]) * 0.5f; mz[q] = (z0 + z1) * 0.5f;
+  }
+  const float incl = wave_incl_prod_dpp(prod);
+  float run = lane_prev(incl, 1.0f);
+  vis = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+  float r = 0.f, g = 0.f, b = 0.f, d = 0.f, w = 0.f;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int i = IPL * lane + q;
+    const float wq = al[q] * run;
+    run *= fk[q];
+    r += wq * mr[q]; g += wq * mg[q]; b += wq * mb[q]; d += wq * mz[q]; w += wq;
+    if (i < n - 1) {
+      if (w_lds) w_lds[i] = wq;
+      if (w_glb) w_glb[i] = wq;
+    }
+  }
+  acc_r = wave_total(r); acc_g = wave_total(g); acc_b = wave_total(b); acc_d = wave_total(d); acc_w = wave_total(w);
+}
+
+__global__ __launch_bounds__(256, 1) void render_generic_kernel(RenderP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  char* lds_b = reinterpret_cast<char*>(lds);
+  char* cimg_w = lds_b + 4 * GEN_WAVE_FLOATS * 4;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.dec);
+    for (int i = threadIdx.x; i < DEC_BYTES / 16; i += blockDim.x) reinterpret_cast<uint4*>(cimg_w)[i] = src[i];
+    __syncthreads();
+  }
+  const char* cimg = cimg_w;
+  float* wf = lds + wid * GEN_WAVE_FLOATS;
+  char* wl = reinterpret_cast<char*>(wf);
+  const int M = p.M, S = p.S, NI = p.NI, NT = S + NI;
+  const int64_t nrays = (int64_t)p.V * M;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float dmin_l = 3.0e38f, dmax_l = -3.0e38f;
+  int cur_grp = -1;
+  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < nrays; ray += nwaves) {
+    const int v = (int)(ray / M), pix = (int)(ray % M);
+    float o[3], d[3];
+    if (p.ray_o) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { o[ax] = p.ray_o[3 * ray + ax]; d[ax] = p.ray_d[3 * ray + ax]; }
+    } else {
+      make_ray(p.cams + 25 * v, p.res, pix, o, d);
+    }
+    const int grp = v / p.vpc;
+    if (grp != cur_grp) {
+      flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
+      dmin_l = 3.0e38f; dmax_l = -3.0e38f; cur_grp = grp;
+    }
+    float t0 = p.t_start, t1 = p.t_end;
+    if (!p.numeric) {
+      const uint32_t* gr = p.scal_u + (int64_t)grp * GRP_WORDS;
+      t0 = p.ray_limits[2 * ray]; t1 = p.ray_limits[2 * ray + 1];
+      if (gr[4] != 0u && !(t1 > t0)) { t0 = dec_f(gr[0]); t1 = dec_f(gr[1]); }    // renderer.py:151-155 (sic)
+    }
+    const float* planes = p.planes + (int64_t)p.plane_index[v] * 3 * p.H * p.W * 32;
+    // sentinels: depths past the sample count compare as +inf in the rank counts and searches
+    wf[G_ZC + lane] = 3.0e38f; wf[G_ZC + 64 + lane] = 3.0e38f; wf[G_ZF + lane] = 3.0e38f; wf[G_ZF + 64 + lane] = 3.0e38f;
+    wave_sync();
+
+    // ---- coarse pass: sample s = lane + 64 j
+    const float delta = (t1 - t0) / (float)(S - 1);
+    float zc[2];
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      const int sidx = lane + 64 * j;
+      if (64 * j >= S) { zc[j] = 3.0e38f; continue; }               // wave-uniform
+      const bool ok = sidx < S;
+      const int sc = ok ? sidx : S - 1;
+      float base;
+      if (p.numeric) {           // torch.linspace (renderer.py:466-470): from the start below the midpoint, from the end above it
+        base = sc < S / 2 ? t0 + delta * (float)sc : t1 - delta * (float)(S - 1 - sc);
+      } else {                   // math_utils.linspace (:121-137): start + i / (num - 1) * (stop - start)
+        base = t0 + ((float)sc / (float)(S - 1)) * (t1 - t0);
+      }
+      const float z = base + p.jitter[ray * S + sc] * delta;
+      float rgb[3], sg;
+      shade64(p, planes, wl, cimg, o[0] + z * d[0], o[1] + z * d[1], o[2] + z * d[2], lane, rgb, sg);
+      zc[j] = ok ? z : 3.0e38f;
+      if (ok) {
+        wf[G_ZC + sidx] = z; wf[G_ZC + GEN_MAXS + sidx] = sg; wf[G_ZC + 2 * GEN_MAXS + sidx] = rgb[0];
+        wf[G_ZC + 3 * GEN_MAXS + sidx] = rgb[1]; wf[G_ZC + 4 * GEN_MAXS + sidx] = rgb[2];
+        dmin_l = fminf(dmin_l, z); dmax_l = fmaxf(dmax_l, z);
+        if (p.coarse_sigma) p.coarse_sigma[ray * S + sidx] = sg;
+        if (p.coarse_coords) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) p.coarse_coords[(ray * S + sidx) * 3 + ax] = o[ax] + z * d[ax];
+        }
+      }
+    }
+    wave_sync();
+    // ---- coarse weights -> importance samples (renderer.py:479-552)
+    {
+      float r_, g_, b_, d_, w_, v_;
+      march_lds<2>(wf + G_ZC, GEN_MAXS, S, lane, wf + G_W, nullptr, r_, g_, b_, d_, w_, v_);
+    }
+    wave_sync();
+    {
+      const float* w = wf + G_W;            // S - 1 weights
+      float wv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;        // pdf entry k takes avg-pooled value k + 1 (weights[:, 1:-1])
+        const bool ok = k < S - 3;
+        const int kk = ok ? k : 0;
+        const float mp0 = fmaxf(w[kk], w[kk + 1]), mp1 = fmaxf(w[kk + 1], w[kk + 2]);
+        const float av = (mp0 + mp1) * 0.5f + 0.01f;
+        wv[j] = ok ? av + 1e-5f : 0.f;
+      }
+      const float tot = wave_total(wv[0] + wv[1]);
+      const float c0 = wave_incl_sum(wv[0] / tot, lane);
+      const float t63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0), 63));
+      const float c1 = wave_incl_sum(wv[1] / tot, lane) + t63;
+      // cdf[0] = 0, cdf[k + 1] = inclusive sum k (k < S - 3): S - 2 entries, +inf behind them
+      if (lane == 0) wf[G_CDF] = 0.f;
+      wf[G_CDF + lane + 1] = lane < S - 3 ? c0 : 3.0e38f;
+      if (lane + 65 < GEN_MAXS) wf[G_CDF + lane + 65] = lane + 64 < S - 3 ? c1 : 3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;
+        const int k0 = k < S - 1 ? k : S - 2;
+        wf[G_BIN + k] = 0.5f * (wf[G_ZC + k0] + wf[G_ZC + k0 + 1]);
+      }
+    }
+    wave_sync();
+    float zf[2];
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      const int fidx = lane + 64 * j;
+      if (64 * j >= NI) { zf[j] = 3.0e38f; continue; }
+      const bool ok = fidx < NI;
+      const float u = p.u_fine[ray * NI + (ok ? fidx : NI - 1)];
+      int pos = 0;                                       // searchsorted(cdf[0 .. S-3], u, right=True): entries <= u
+#pragma unroll
+      for (int s2 = 64; s2 >= 1; s2 >>= 1) pos += (wf[G_CDF + pos + s2 - 1] <= u) ? s2 : 0;
+      pos += (wf[G_CDF + pos] <= u) ? 1 : 0;
+      const int below = pos - 1 < 0 ? 0 : pos - 1;
+      const int above = pos > S - 3 ? S - 3 : pos;         // clamp_max(N_samples_ = S - 3)
+      const float cb = wf[G_CDF + below], ca = wf[G_CDF + above], bb = wf[G_BIN + below], ba = wf[G_BIN + above];
+      float den = ca - cb;
+      den = den < 1e-5f ? 1.0f : den;
+      const float z = bb + (u - cb) / den * (ba - bb);
+      float rgb[3], sg;
+      shade64(p, planes, wl, cimg, o[0] + z * d[0], o[1] + z * d[1], o[2] + z * d[2], lane, rgb, sg);
+      zf[j] = ok ? z : 3.0e38f;
+      if (ok) {
+        wf[G_ZF + fidx] = z; wf[G_ZF + GEN_MAXS + fidx] = sg; wf[G_ZF + 2 * GEN_MAXS + fidx] = rgb[0];
+        wf[G_ZF + 3 * GEN_MAXS + fidx] = rgb[1]; wf[G_ZF + 4 * GEN_MAXS + fidx] = rgb[2];
+        dmin_l = fminf(dmin_l, z); dmax_l = fmaxf(dmax_l, z);
+        if (p.fine_depths) p.fine_depths[ray * NI + fidx] = z;
+        if (p.fine_sigma) p.fine_sigma[ray * NI + fidx] = sg;
+        if (p.fine_coords) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) p.fine_coords[(ray * NI + fidx) * 3 + ax] = o[ax] + z * d[ax];
+        }
+      }
+    }
+    wave_sync();
+    // ---- unify_samples (renderer.py:422-435): rank of every sample in the stable order of cat([coarse, fine]) by depth
+    {
+      int rk[4] = {0, 0, 0, 0};
+      const float ze[4] = {zc[0], zc[1], zf[0], zf[1]};
+      const int ce[4] = {lane, lane + 64, S + lane, S + lane + 64};          // index in the concatenation
+      const int S4 = (S + 3) & ~3, N4 = (NI + 3) & ~3;
+#pragma unroll 1
+      for (int k = 0; k < S4; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(wf + G_ZC + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rk[e] += (a.x < ze[e] || (a.x == ze[e] && k + 0 < ce[e])) + (a.y < ze[e] || (a.y == ze[e] && k + 1 < ce[e])) +
+                   (a.z < ze[e] || (a.z == ze[e] && k + 2 < ce[e])) + (a.w < ze[e] || (a.w == ze[e] && k + 3 < ce[e]));
+      }
+#pragma unroll 1
+      for (int k = 0; k < N4; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(wf + G_ZF + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rk[e] += (a.x < ze[e] || (a.x == ze[e] && S + k + 0 < ce[e])) + (a.y < ze[e] || (a.y == ze[e] && S + k + 1 < ce[e])) +
+                   (a.z < ze[e] || (a.z == ze[e] && S + k + 2 < ce[e])) + (a.w < ze[e] || (a.w == ze[e] && S + k + 3 < ce[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int li = lane + 64 * (e & 1);
+        const bool ok = (e < 2) ? li < S : li < NI;
+        const float* src = wf + (e < 2 ? G_ZC : G_ZF) + li;
+        if (ok && rk[e] < NT) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c) wf[G_SRT + c * 2 * GEN_MAXS + rk[e]] = src[c * GEN_MAXS];
+        }
+      }
+    }
+    wave_sync();
+    float acc_r, acc_g, acc_b, acc_d, acc_w, vis;
+    march_lds<4>(wf + G_SRT, 2 * GEN_MAXS, NT, lane, nullptr, p.w_all ? p.w_all + ray * (NT - 1) : nullptr, acc_r, acc_g, acc_b, acc_d, acc_w, vis);
+    if (p.coords_all || p.colors_all) {
+      for (int i = lane; i < NT; i += 64) {
+        const float z = wf[G_SRT + i];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          if (p.coords_all) p.coords_all[(ray * NT + i) * 3 + ax] = o[ax] + z * d[ax];
+          if (p.colors_all) p.colors_all[(ray * NT + i) * 3 + ax] = wf[G_SRT + (2 + ax) * 2 * GEN_MAXS + i];
+        }
+      }
+    }
+    if (lane == 0) {
+      if (p.white_back) { acc_r += 1.0f - acc_w; acc_g += 1.0f - acc_w; acc_b += 1.0f - acc_w; }
+      const int64_t img = (int64_t)v * 3 * M;
+      p.rgb[img + pix] = acc_r * 2.0f - 1.0f;
+      p.rgb[img + M + pix] = acc_g * 2.0f - 1.0f;
+      p.rgb[img + 2 * M + pix] = acc_b * 2.0f - 1.0f;
+      p.depth[ray] = acc_d;          // clamped by render_finalize_kernel
+      p.wsum[ray] = acc_w;
+      if (p.vis) p.vis[ray] = vis;
+    }
+    wave_sync();
+  }
+  flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
+}
+
 extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   if (!a || !a->planes || !a->plane_index || !a->jitter || !a->u_fine || !a->rgb || !a->depth || !a->wsum ||
       !a->ray_limits || !a->scalars || !a->dec_w0 || !a->dec_b0 || !a->dec_w1 || !a->dec_b1)
     return LN3D_ERR_BAD_ARG;
-  if (a->V <= 0 || a->res <= 0) return LN3D_ERR_BAD_ARG;
+  if (a->V <= 0 || (a->res <= 0 && a->rays_per_view <= 0)) return LN3D_ERR_BAD_ARG;
   if (!a->cams && !(a->ray_o && a->ray_d)) return LN3D_ERR_BAD_ARG;       // cameras, or explicit rays
   if ((a->ray_o != nullptr) != (a->ray_d != nullptr)) return LN3D_ERR_BAD_ARG;
+  if (a->rays_per_view > 0 && !a->ray_o && a->rays_per_view != a->res * a->res) return LN3D_ERR_BAD_ARG;   // camera rays are a res x res image
+  const int S = a->depth_resolution > 0 ? a->depth_resolution : NS, NI = a->depth_resolution_importance > 0 ? a->depth_resolution_importance : NS;
+  if (S < 4 || S > GEN_MAXS || NI < 1 || NI > GEN_MAXS) return LN3D_ERR_UNSUPPORTED;
+  if (a->ray_mode != 0 && !(a->ray_end > a->ray_start)) return LN3D_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   RenderP p;
   p.planes = a->planes; p.H = a->H; p.W = a->W; p.plane_index = a->plane_index; p.cams = a->cams; p.V = a->V; p.res = a->res;
+  p.M = a->rays_per_view > 0 ? a->rays_per_view : a->res * a->res;
   p.jitter = a->jitter; p.u_fine = a->u_fine;
-  p.coord_scale = (float)(2.0 / (double)a->box_warp); p.bbox_min = a->bbox_min; p.bbox_max = a->bbox_max; p.white_back = a->white_back;
+  p.coord_scale = (float)(2.0 / (double)a->box_warp); p.white_back = a->white_back;
+  p.bbox_min = a->no_bbox_filter ? -3.0e38f : a->bbox_min; p.bbox_max = a->no_bbox_filter ? 3.0e38f : a->bbox_max;
   p.rgb = a->rgb; p.depth = a->depth; p.wsum = a->wsum; p.ray_limits = a->ray_limits;
   p.scal_u = reinterpret_cast<uint32_t*>(a->scalars) + GRP_OFF; p.dec = a->scalars + DEC_OFF;
   p.vpc = (a->views_per_call <= 0 || a->views_per_call > a->V) ? a->V : a->views_per_call;
@@ -681,18 +958,34 @@ extern "C" int ln3d_render_triplane(const ln3d_render_args* a, void* stream) {
   if (groups > MAX_GROUPS) return LN3D_ERR_BAD_ARG;             // render in chunks of <= MAX_GROUPS calls
   p.coarse_sigma = a->coarse_sigma; p.fine_depths = a->fine_depths;
   p.ray_o = a->ray_o; p.ray_d = a->ray_d; p.fine_sigma = a->fine_sigma; p.coarse_coords = a->coarse_coords; p.fine_coords = a->fine_coords;
-  const int64_t nrays = (int64_t)a->V * a->res * a->res;
-  static AttrOnce attr_once;
-  if (attr_once.need()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_K_LDS_BYTES);
-  }
+  p.vis = a->visibility;
+  p.S = S; p.NI = NI; p.numeric = a->ray_mode != 0; p.t_start = a->ray_start; p.t_end = a->ray_end;
+  p.w_all = a->weights; p.coords_all = a->all_coords; p.colors_all = a->feature_volume;
+  const int64_t nrays = (int64_t)a->V * p.M;
+  // the lane = sample kernel serves the Objaverse preset; everything else (and the return_meta outputs) the generic one
+  const bool fast = S == NS && NI == NS && !p.numeric && !a->no_bbox_filter && !p.w_all && !p.coords_all && !p.colors_all;
   hipLaunchKernelGGL(render_init_kernel, dim3(8), dim3(256), 0, s, p.scal_u, groups, a->scalars + DEC_OFF, a->dec_w0, a->dec_b0, a->dec_w1, a->dec_b1);
-  hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
-  int64_t blocks = (nrays + RENDER_WPB - 1) / RENDER_WPB;
-  const int64_t cap = 256 * 8 * 4 / RENDER_WPB;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(64 * RENDER_WPB), RENDER_K_LDS_BYTES, s, p);
-  hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays, (int64_t)p.vpc * a->res * a->res);
+  if (!p.numeric)
+    hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, p, a->box_warp * 0.5f);
+  if (fast) {
+    static AttrOnce attr_once;
+    if (attr_once.need()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RENDER_K_LDS_BYTES);
+    }
+    int64_t blocks = (nrays + RENDER_WPB - 1) / RENDER_WPB;
+    const int64_t cap = 256 * 8 * 4 / RENDER_WPB;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(64 * RENDER_WPB), RENDER_K_LDS_BYTES, s, p);
+  } else {
+    static AttrOnce attr_once;
+    if (attr_once.need()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES);
+    }
+    int64_t blocks = (nrays + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    hipLaunchKernelGGL(render_generic_kernel, dim3((unsigned)blocks), dim3(256), GEN_LDS_BYTES, s, p);
+  }
+  hipLaunchKernelGGL(render_finalize_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, s, a->depth, p.scal_u, nrays, (int64_t)p.vpc * p.M);
   return ln3d_check_launch();
 }
 

@@ -2,18 +2,18 @@
 
 Mirrors the reference's nsr/triplane.py `Triplane` (forward(planes, c) -> dict with image_raw,
 image_depth, weights_samples, image_mask, ...) and `OSGDecoder` (state-dict keys
-`decoder.net.{0,2}.{weight,bias}`) for the Objaverse rendering preset
-(nsr/script_util.py:761-798: 64 + 64 samples, box_warp 0.9, bbox +-0.45, white background,
-auto ray limits).  ray generation, sampling, gather, MLP and compositing all run inside
-`ln3d_render_triplane` (csrc/render.hip) - nothing of the reference's [V,3,M*S,32] feature tensor
-or its sort/gather intermediates is ever materialised.
+`decoder.net.{0,2}.{weight,bias}`).  rendering_kwargs: any sampling preset of nsr/script_util.py:433-1000
+(volumetric_rendering/renderer.py lists what is taken); the default is the Objaverse preset (:761-798: 64 + 64
+samples, box_warp 0.9, bbox +-0.45, white background, auto ray limits).  ray generation, sampling, gather, MLP
+and compositing all run inside `ln3d_render_triplane` (csrc/render.hip) - nothing of the reference's
+[V,3,M*S,32] feature tensor or its sort/gather intermediates is ever materialised.
 """
 import torch
 import torch.nn as nn
 
 from .. import ops, _cache
 from .._lib import RENDER_SCRATCH_FLOATS, RENDER_MAX_CALLS
-from .volumetric_rendering.renderer import ImportanceRenderer, check_rendering_options, draw_render_noise  # noqa: F401
+from .volumetric_rendering.renderer import ImportanceRenderer, check_rendering_options, draw_render_noise, render_call_kwargs  # noqa: F401
 
 
 class FullyConnectedLayer(nn.Module):      # nsr/networks_stylegan2.py:122-157 (container; gain applied in-kernel)
@@ -105,16 +105,16 @@ class Triplane(nn.Module):
         if not c.is_cuda:
             raise RuntimeError("ln3diff_amd.Triplane runs on the HIP device only (no CPU fallback)")
         dev = c.device
-        V, M, S = c.shape[0], res * res, 64
+        rk = self.rendering_kwargs
+        V, M, S, NI = c.shape[0], res * res, rk.get('depth_resolution', 64), rk.get('depth_resolution_importance', 64)
         if planes_channel_last is None:
             planes_channel_last = self.to_channel_last(planes)
             plane_index = torch.arange(V, device=dev, dtype=torch.int32)
         H, W = planes_channel_last.shape[2], planes_channel_last.shape[3]
         if jitter is None:
-            jitter, u_fine = draw_render_noise(V, M, S, device=dev)
+            jitter, u_fine = draw_render_noise(V, M, S, device=dev, n_importance=NI)
         jitter = jitter.to(dev, torch.float32).reshape(V, M, S).contiguous()
-        u_fine = u_fine.to(dev, torch.float32).reshape(V * M, S).contiguous()
-        rk = self.rendering_kwargs
+        u_fine = u_fine.to(dev, torch.float32).reshape(V * M, NI).contiguous()
         rgb = torch.empty(V, 3, res, res, device=dev)
         depth = torch.empty(V, 1, res, res, device=dev)
         wsum = torch.empty(V, 1, res, res, device=dev)
@@ -124,10 +124,10 @@ class Triplane(nn.Module):
         # view, so only on request - rendering_kwargs['return_sampling_details_flag'] (the reference preset sets it) or return_debug
         details = bool(rk.get('return_sampling_details_flag', False))
         cs = torch.empty(V, M, S, device=dev) if (return_debug or details) else None
-        fd = torch.empty(V, M, S, device=dev) if return_debug else None
-        fs = torch.empty(V, M, S, device=dev) if details else None
+        fd = torch.empty(V, M, NI, device=dev) if return_debug else None
+        fs = torch.empty(V, M, NI, device=dev) if details else None
         cc = torch.empty(V, M, S, 3, device=dev) if details else None
-        fc = torch.empty(V, M, S, 3, device=dev) if details else None
+        fc = torch.empty(V, M, NI, 3, device=dev) if details else None
         pidx = plane_index.to(dev, torch.int32).contiguous()
         cam = c.to(torch.float32).contiguous()
         # one launch handles at most RENDER_MAX_CALLS reference calls (range records in the scratch): more are rendered in chunks of
@@ -138,17 +138,16 @@ class Triplane(nn.Module):
         for a in range(0, V, chunk):
             b = min(V, a + chunk)
             ops.render_triplane(planes_channel_last, H, W, pidx[a:b], cam[a:b], res, self._decoder_dev(dev), jitter[a:b], u_fine[a * M:b * M],
-                                rgb[a:b], depth[a:b], wsum[a:b], lim, scal, box_warp=rk['box_warp'], bbox_min=rk['sampler_bbox_min'],
-                                bbox_max=rk['sampler_bbox_max'], white_back=rk.get('white_back', True), coarse_sigma=sl(cs, a, b),
+                                rgb[a:b], depth[a:b], wsum[a:b], lim, scal, coarse_sigma=sl(cs, a, b),
                                 fine_depths=sl(fd, a, b), fine_sigma=sl(fs, a, b), coarse_coords=sl(cc, a, b), fine_coords=sl(fc, a, b),
-                                views_per_call=views_per_call if chunk == V else vpc)
+                                views_per_call=views_per_call if chunk == V else vpc, **render_call_kwargs(rk))
         ret = {'feature_image': rgb, 'image_raw': rgb, 'image_depth': depth, 'weights_samples': wsum,
                'image_mask': wsum * (1 + 2 * 0.001) - 0.001,
                'shape_synthesized': {'image_depth': depth, 'depth': depth.reshape(V, M, 1)}}
         if return_debug:
             ret['shape_synthesized'].update(coarse_densities=cs.unsqueeze(-1), fine_depths=fd.unsqueeze(-1))
         if details:
-            ret['shape_synthesized'].update(coarse_coords=cc, coarse_densities=cs.unsqueeze(-1), fine_coords=fc.reshape(V, M * S, 3),
+            ret['shape_synthesized'].update(coarse_coords=cc, coarse_densities=cs.unsqueeze(-1), fine_coords=fc.reshape(V, M * NI, 3),
                                             fine_densities=fs.unsqueeze(-1))
         return ret
 

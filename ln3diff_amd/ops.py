@@ -155,10 +155,12 @@ def planes_to_nchw(src, dst, NP, Cc, H, W):
 
 def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine, rgb, depth, wsum, ray_limits, scalars,
                     box_warp=0.9, bbox_min=-0.45, bbox_max=0.45, white_back=True, coarse_sigma=None, fine_depths=None,
-                    ray_o=None, ray_d=None, fine_sigma=None, coarse_coords=None, fine_coords=None, n_views=None, views_per_call=0):
-    """cams [V,25] (rays generated in-kernel) or explicit ray_o / ray_d [V, res*res, 3] (then cams may be None).
+                    ray_o=None, ray_d=None, fine_sigma=None, coarse_coords=None, fine_coords=None, n_views=None, views_per_call=0,
+                    rays_per_view=0, visibility=None, depth_resolution=0, depth_resolution_importance=0, ray_start='auto', ray_end='auto',
+                    filter_out_of_bbox=True, weights=None, all_coords=None, feature_volume=None):
+    """cams [V,25] (rays generated in-kernel) or explicit ray_o / ray_d [V, M, 3] (then cams may be None; rays_per_view = M).
     views_per_call: how many consecutive views form one reference forward() call for the call-wide reductions (ray-limit fix-up,
-    depth clamp range); 0 = all of them (include/ln3d.h)."""
+    depth clamp range); 0 = all of them (include/ln3d.h).  ray_start / ray_end: both 'auto' or both numbers."""
     a = L.RenderArgs()
     a.planes, a.H, a.W, a.plane_index, a.cams = _p(planes_cl), H, W, _p(plane_index), _p(cams)
     a.V, a.res = (cams.shape[0] if cams is not None else n_views), res
@@ -169,6 +171,16 @@ def render_triplane(planes_cl, H, W, plane_index, cams, res, dec, jitter, u_fine
     a.coarse_sigma, a.fine_depths = _p(coarse_sigma), _p(fine_depths)
     a.ray_o, a.ray_d, a.fine_sigma, a.coarse_coords, a.fine_coords = _p(ray_o), _p(ray_d), _p(fine_sigma), _p(coarse_coords), _p(fine_coords)
     a.views_per_call = int(views_per_call)
+    a.rays_per_view, a.visibility = int(rays_per_view), _p(visibility)
+    a.depth_resolution, a.depth_resolution_importance = int(depth_resolution), int(depth_resolution_importance)
+    if (ray_start == 'auto') != (ray_end == 'auto'):
+        raise ValueError("ray_start / ray_end: both 'auto' or both numbers (renderer.py:145)")
+    if ray_start == 'auto':
+        a.ray_mode = 0
+    else:
+        a.ray_mode, a.ray_start, a.ray_end = 1, float(ray_start), float(ray_end)
+    a.no_bbox_filter = 0 if filter_out_of_bbox else 1
+    a.weights, a.all_coords, a.feature_volume = _p(weights), _p(all_coords), _p(feature_volume)
     L.check(L.lib().ln3d_render_triplane(C.byref(a), _stream()), "render_triplane")
 
 

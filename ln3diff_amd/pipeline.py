@@ -80,10 +80,12 @@ def render_pairs(latent_all, rec_model, cams, pairs, triplane_scaling_divider=TR
     pair_index = torch.tensor([(s, v) for s, v0, v1 in pairs for v in range(v0, v1)], dtype=torch.int64, device=dev)
     jitter = u_fine = None
     if noise_seed is not None:
+        rk_ = rec_model.decoder.triplane_decoder.rendering_kwargs
         js, us = [], []
         for s, v in pair_index.tolist():
             g = torch.Generator(device=dev).manual_seed(int(noise_seed) + s * V_all + v)
-            j, u = draw_render_noise(1, res * res, 64, generator=g, device=dev)
+            j, u = draw_render_noise(1, res * res, rk_.get('depth_resolution', 64), generator=g, device=dev,
+                                     n_importance=rk_.get('depth_resolution_importance', 64))
             js.append(j)
             us.append(u)
         jitter, u_fine = torch.cat(js), torch.cat(us)

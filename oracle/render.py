@@ -29,6 +29,19 @@ OBJAVERSE_OPTS = dict(  # nsr/script_util.py:761-798 as probed in SURVEY.md App.
     clamp_mode='softplus', ray_start='auto', ray_end='auto', disparity_space_sampling=False)
 
 
+SHAPENET_OPTS = dict(  # nsr/script_util.py 'shapenet_tuneray_aug_resolution_64_64_nearestSR' with the released --ray_start 0.6 --ray_end 1.8
+    depth_resolution=64, depth_resolution_importance=64, ray_start=0.6, ray_end=1.8, box_warp=1.2, white_back=True,
+    clamp_mode='softplus', disparity_space_sampling=False)
+OBJAVERSE_128_OPTS = dict(OBJAVERSE_OPTS, depth_resolution=128, depth_resolution_importance=128)   # 'objverse_tuneray_aug_resolution_128_128_auto'
+OBJAVERSE_96_OPTS = dict(OBJAVERSE_OPTS, depth_resolution=96, depth_resolution_importance=96)      # '..._96_96_auto'
+EG3D_80_OPTS = dict(  # 'eg3d_shapenet_aug_resolution': 80 + 80, numeric limits, box_warp 1.1
+    depth_resolution=80, depth_resolution_importance=80, ray_start=0.1, ray_end=1.9, box_warp=1.1, white_back=True,
+    clamp_mode='softplus', disparity_space_sampling=False)
+AFHQ_48_OPTS = dict(  # 'afhq' / 'ffhq': 48 + 48, ray_start 2.25, ray_end 3.3, box_warp 1, black background
+    depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1, white_back=False,
+    clamp_mode='softplus', disparity_space_sampling=False)
+
+
 def make_rays(c, res):
     """c [V,25] = 16 cam2world + 9 intrinsics -> ray_o, ray_d [V, res*res, 3]."""
     V = c.shape[0]
@@ -199,19 +212,31 @@ def sample_pdf(bins, weights, n_imp, u, eps=1e-5):
     return bins_g[..., 0] + (u - cdf_g[..., 0]) / denom * (bins_g[..., 1] - bins_g[..., 0])
 
 
+def numeric_depths(ray_start, ray_end, S, jitter):
+    """renderer.py:463-474 (ray_start / ray_end as numbers): torch.linspace + rand * delta.  jitter [V,M,S,1]."""
+    z = torch.linspace(ray_start, ray_end, S).reshape(1, 1, S, 1)
+    delta = (ray_end - ray_start) / (S - 1)
+    return z + jitter * delta
+
+
 def render(planes, dec_sd, ray_o, ray_d, jitter, u_fine, opts=OBJAVERSE_OPTS):
-    """ImportanceRenderer.forward.  planes [V,3,C,H,W] (one tri-plane per view row)."""
+    """ImportanceRenderer.forward (renderer.py:133-307).  planes [V,3,C,H,W] (one tri-plane per view row).
+    Also returns what `return_meta` adds (:283-300): weights [V,M,S+NI-1,1], all_coords [V,M,S+NI,3], feature_volume."""
     V, M, _ = ray_o.shape
     S, NI = opts['depth_resolution'], opts['depth_resolution_importance']
-    start, end = auto_ray_range(ray_o, ray_d, opts['box_warp'])
-    z_c = stratified_depths(start, end, S, jitter)
+    if opts['ray_start'] == opts['ray_end'] == 'auto':
+        start, end = auto_ray_range(ray_o, ray_d, opts['box_warp'])
+        z_c = stratified_depths(start, end, S, jitter)
+    else:
+        z_c = numeric_depths(opts['ray_start'], opts['ray_end'], S, jitter).expand(V, M, S, 1).contiguous()
     pts = (ray_o.unsqueeze(-2) + z_c * ray_d.unsqueeze(-2)).reshape(V, -1, 3)
     fb = opts.get('filter_out_of_bbox', False)
+    wb = opts.get('white_back', True)
     rgb_c, sig_c = run_model(planes, dec_sd, pts, opts, fb)
     rgb_c, sig_c = rgb_c.reshape(V, M, S, -1), sig_c.reshape(V, M, S, 1)
-    out = dict(coarse_depths=z_c, coarse_densities=sig_c, coarse_colors=rgb_c)
+    out = dict(coarse_depths=z_c, coarse_densities=sig_c, coarse_colors=rgb_c, coarse_coords=pts.reshape(V, M, S, 3))
     if NI > 0:
-        _, _, _, w_c = ray_march(rgb_c, sig_c, z_c, opts['white_back'])
+        _, _, _, w_c = ray_march(rgb_c, sig_c, z_c, wb)
         z_f = sample_importance(z_c, w_c, NI, u_fine)
         pts_f = (ray_o.unsqueeze(-2) + z_f * ray_d.unsqueeze(-2)).reshape(V, -1, 3)
         rgb_f, sig_f = run_model(planes, dec_sd, pts_f, opts, fb)
@@ -223,11 +248,13 @@ def render(planes, dec_sd, ray_o, ray_d, jitter, u_fine, opts=OBJAVERSE_OPTS):
         z_all = torch.gather(z_all, -2, idx)
         rgb_all = torch.gather(rgb_all, -2, idx.expand(-1, -1, -1, rgb_all.shape[-1]))
         sig_all = torch.gather(sig_all, -2, idx)
-        rgb, depth, vis, w = ray_march(rgb_all, sig_all, z_all, opts['white_back'])
-        out.update(fine_depths=z_f, fine_densities=sig_f, coarse_weights=w_c)
+        rgb, depth, vis, w = ray_march(rgb_all, sig_all, z_all, wb)
+        coords_all = torch.gather(torch.cat([pts.reshape(V, M, S, 3), pts_f.reshape(V, M, NI, 3)], -2), -2, idx.expand(-1, -1, -1, 3))
+        out.update(fine_depths=z_f, fine_densities=sig_f, coarse_weights=w_c, fine_coords=pts_f.reshape(V, M, NI, 3),
+                   all_coords=coords_all, feature_volume=rgb_all, all_depths=z_all)
     else:
-        rgb, depth, vis, w = ray_march(rgb_c, sig_c, z_c, opts['white_back'])
-    out.update(rgb=rgb, depth=depth, weights_sum=w.sum(2), visibility=vis)
+        rgb, depth, vis, w = ray_march(rgb_c, sig_c, z_c, wb)
+    out.update(rgb=rgb, depth=depth, weights_sum=w.sum(2), visibility=vis, weights=w)
     return out
 
 

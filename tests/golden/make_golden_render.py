@@ -119,6 +119,87 @@ def sec_render():
     save('grid16', sigma=out['sigma'].reshape(G, G, G), rgb=out['rgb'].reshape(G, G, G, 3))
 
 
+PRESETS = {  # tag -> (oracle options, res, V, cameras' orbit radius): the sampling presets of nsr/script_util.py the entry points select
+    'shapenet64': (orender.SHAPENET_OPTS, 16, 2, 1.2),
+    'objv128': (orender.OBJAVERSE_128_OPTS, 16, 2, 1.7719),
+    'objv96': (orender.OBJAVERSE_96_OPTS, 12, 1, 1.7719),
+    'eg3d80': (orender.EG3D_80_OPTS, 12, 2, 1.2),
+    'afhq48': (orender.AFHQ_48_OPTS, 12, 1, 2.7),
+}
+
+
+def ref_preset_kwargs(opts):
+    """rendering_options_defaults (nsr/script_util.py:433-465) + the preset's keys; return_sampling_details_flag to get the per-sample
+    tensors and, through it, return_meta (nsr/triplane.py:575-576)."""
+    rk = dict(image_resolution=256, disparity_space_sampling=False, clamp_mode='softplus', c_gen_conditioning_zero=True, c_scale=1,
+              superresolution_noise_mode='none', density_reg=0.25, density_reg_p_dist=0.004, reg_type='l1', decoder_lr_mul=1,
+              decoder_activation='sigmoid', sr_antialias=True, return_triplane_features=False, return_sampling_details_flag=True)
+    rk.update(opts)
+    return rk
+
+
+def sec_render_presets():
+    """The reference's Triplane.forward under the other rendering presets (numeric ray limits, 48 - 128 samples, no bbox filter,
+    black background) and the seam outputs of ImportanceRenderer.forward(return_meta=True): visibility, weights, all_coords,
+    feature_volume - against oracle.render, saved as fixtures."""
+    mg = _mg()
+    check, save = mg.check, mg.save
+    print('== renderer presets + return_meta (reference Triplane.forward vs oracle.render)')
+    from nsr.triplane import Triplane
+    cases = dict(PRESETS, objv64_meta=(orender.OBJAVERSE_OPTS, 16, 2, 1.7719))
+    for tag, (opts, res, V, radius) in cases.items():
+        rk = ref_preset_kwargs(opts)
+        if 'auto' in str(opts['ray_start']):
+            rk.update(PatchRaySampler=True, patch_rendering_resolution=45)       # the Objaverse presets carry it (:788)
+        tp = Triplane(25, res, 3, rendering_kwargs=rk, out_chans=96, triplane_size=224, decoder_in_chans=32, decoder_output_dim=3,
+                      sr_kwargs={}, bcg_synthesis_kwargs={}, lrm_decoder=False).eval()
+        sd = dense_decoder_sd(0)
+        tp.decoder.load_state_dict(sd, strict=True)
+        planes = synth_input('planes', (V, 96, 128, 128), 3, 4.0)
+        cams = orbit_cameras(8, radius=radius)[[1, 6][:V]]
+        M, S, NI = res * res, opts['depth_resolution'], opts['depth_resolution_importance']
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r_ref = tp(planes, cams)
+        # the reference's RNG stream -> logical tensors: the 'auto' branch draws on a [S,V,M,1]-strided tensor (SURVEY App. A.13),
+        # the numeric branch on the contiguous [V,M,S,1] repeat (renderer.py:466-471)
+        torch.manual_seed(0)
+        if opts['ray_start'] == 'auto':
+            jitter = torch.rand(S, V, M, 1).permute(1, 2, 0, 3).contiguous()
+        else:
+            jitter = torch.rand(V, M, S, 1)
+        u_fine = torch.rand(V * M, NI)
+        o_ref, d_ref, _ = tp.ray_sampler(cams[:, :16].reshape(-1, 4, 4), cams[:, 16:25].reshape(-1, 3, 3), res, res)
+        o, d = orender.make_rays(cams, res)
+        check(f'{tag} ray origins', o, o_ref, 1e-6)
+        check(f'{tag} ray dirs', d, d_ref, 1e-6)
+        r = orender.triplane_render(planes, sd, cams, res, jitter, u_fine, opts)
+        det = r['detail']
+        ss = r_ref['shape_synthesized']
+        check(f'{tag} coarse densities', det['coarse_densities'], ss['coarse_densities'], 1e-4)
+        check(f'{tag} fine densities', det['fine_densities'], ss['fine_densities'], 1e-4)
+        check(f'{tag} coarse coords', det['coarse_coords'], ss['coarse_coords'], 1e-5)
+        check(f'{tag} image_raw', r['image_raw'], r_ref['image_raw'], 1e-4)
+        check(f'{tag} image_depth', r['image_depth'], r_ref['image_depth'], 1e-4)
+        check(f'{tag} weights_samples', r['weights_samples'], r_ref['weights_samples'], 1e-4)
+        check(f'{tag} weights', det['weights'], r_ref['weights'], 1e-4)
+        check(f'{tag} all_coords', det['all_coords'], r_ref['all_coords'], 1e-5)
+        check(f'{tag} feature_volume', det['feature_volume'], r_ref['feature_volume'], 1e-4)
+        # 'visibility' only leaves ImportanceRenderer.forward (renderer.py:281): call the seam itself on the same RNG stream
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r_seam = tp.renderer(planes.reshape(V, 3, 32, 128, 128), tp.decoder, o_ref, d_ref, tp.rendering_kwargs, return_meta=True)
+        check(f'{tag} seam feature_samples == Triplane.forward', r_seam['feature_samples'].permute(0, 2, 1).reshape(V, 3, res, res), r_ref['image_raw'], 1e-7)
+        check(f'{tag} visibility', det['visibility'], r_seam['visibility'], 1e-4)
+        print(f'   {tag}: S {S} NI {NI} mask mean {float(r_ref["image_mask"].mean()):.3f} depth range '
+              f'[{float(r_ref["image_depth"].min()):.4f},{float(r_ref["image_depth"].max()):.4f}] visibility mean {float(r_seam["visibility"].mean()):.3f}')
+        save(f'render_preset_{tag}', image_raw=r_ref['image_raw'], image_depth=r_ref['image_depth'], weights_samples=r_ref['weights_samples'],
+             image_mask=r_ref['image_mask'], visibility=r_seam['visibility'], weights=r_ref['weights'].half(),
+             all_coords=r_ref['all_coords'].half(), feature_volume=r_ref['feature_volume'].half(),
+             coarse_densities=ss['coarse_densities'].half(), fine_depths=det['fine_depths'].half(), cams=cams, jitter_seed=np.array(0),
+             plane_scale=np.array(4.0), sigma_bias=np.array(4.0), res=np.array(res), radius=np.array(radius))
+
+
 # ------------------------------------------------------------------ VAE decode
 def build_decoder(hidden, depth, heads):
     """The released decoder class (vit/vit_triplane.py:1982) around a DiT2 of the given size."""

@@ -112,3 +112,103 @@ def test_render_is_bitwise_repeatable_over_scenes(hip_lib):
             o = f()
             for k in ('image_raw', 'image_depth', 'weights_samples'):
                 assert torch.equal(ref[k], o[k]), (V, res, el, rad, k)
+
+
+PRESET_OPTS = {'shapenet64': 'SHAPENET_OPTS', 'objv128': 'OBJAVERSE_128_OPTS', 'objv96': 'OBJAVERSE_96_OPTS', 'eg3d80': 'EG3D_80_OPTS',
+               'afhq48': 'AFHQ_48_OPTS', 'objv64_meta': 'OBJAVERSE_OPTS'}
+
+
+def _preset_scene(tag):
+    from oracle import render as orender
+    from ln3diff_amd.nsr.triplane import Triplane, draw_render_noise
+    from ln3diff_amd.synth import synth_input
+    g = golden('render_preset_' + tag)
+    opts = dict(getattr(orender, PRESET_OPTS[tag]))
+    res = int(g['res'])
+    tp = Triplane(img_resolution=res, rendering_kwargs=dict(opts, return_sampling_details_flag=True))
+    tp.decoder.load_state_dict(_decoder_sd(float(g['sigma_bias'])))
+    tp = tp.cuda()
+    cams = torch.from_numpy(g['cams'])
+    V, M, S, NI = cams.shape[0], res * res, opts['depth_resolution'], opts['depth_resolution_importance']
+    planes = synth_input('planes', (V, 96, 128, 128), 3, float(g['plane_scale']))
+    gen = torch.Generator().manual_seed(int(g['jitter_seed']))
+    if opts['ray_start'] == 'auto':                                  # RNG order of the two branches of sample_stratified (renderer.py:455-474)
+        jitter, u_fine = draw_render_noise(V, M, S, generator=gen, n_importance=NI)
+    else:
+        jitter = torch.rand(V, M, S, 1, generator=gen).reshape(V, M, S)
+        u_fine = torch.rand(V * M, NI, generator=gen)
+    return g, tp, opts, planes, cams, jitter, u_fine, (V, M, S, NI, res)
+
+
+@pytest.mark.parametrize("tag", ['shapenet64', 'objv128', 'objv96', 'eg3d80', 'afhq48'])
+def test_render_presets_vs_reference_golden(hip_lib, tag):
+    """The other sampling presets of nsr/script_util.py:433-1000 (numeric ray_start / ray_end, 48 - 128 samples per pass, no bbox
+    filter, black background) through Triplane.forward, against the reference's own outputs (tests/golden/make_golden_render.py
+    sec_render_presets; oracle == reference <= 1e-4 there)."""
+    g, tp, opts, planes, cams, jitter, u_fine, (V, M, S, NI, res) = _preset_scene(tag)
+    out = tp(planes.cuda(), cams.cuda(), jitter=jitter, u_fine=u_fine, return_debug=True)
+    ss = out['shape_synthesized']
+    assert ss['coarse_coords'].shape == (V, M, S, 3) and ss['fine_coords'].shape == (V, M * NI, 3)
+    cd = ss['coarse_densities'].cpu().reshape(-1)
+    cd_ref = torch.from_numpy(g['coarse_densities'].astype(np.float32)).reshape(-1)
+    inb = cd_ref > -1e30
+    assert torch.equal(cd > -1e30, inb)
+    assert rel_l2(cd[inb], cd_ref[inb]) < 2e-3                      # fp16-stored golden
+    assert rel_l2(ss['fine_depths'].cpu().reshape(-1), torch.from_numpy(g['fine_depths'].astype(np.float32)).reshape(-1)) < 2e-3
+    for key in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
+        e = rel_l2(out[key].cpu(), g[key])
+        print(tag, key, e)
+        assert e < 2e-3, (key, e)
+
+
+@pytest.mark.parametrize("tag", ['objv64_meta', 'shapenet64', 'objv128'])
+def test_importance_renderer_seam_outputs_vs_reference_golden(hip_lib, tag):
+    """ImportanceRenderer.forward(planes, decoder, ray_origins, ray_directions, rendering_options, return_meta=True) - the reference's
+    positional signature - returns the reference's keys (renderer.py:276-300): visibility, and under return_meta weights / all_coords
+    / feature_volume; rays as a LIST (M not a square number) give the same per-ray values."""
+    from oracle import render as orender
+    g, tp, opts, planes, cams, jitter, u_fine, (V, M, S, NI, res) = _preset_scene(tag)
+    ro, rd = (t.cuda() for t in orender.make_rays(cams, res))
+    pl = planes.cuda().view(V, 3, 32, 128, 128)
+    out = tp.renderer(pl, tp.decoder, ro, rd, tp.rendering_kwargs, True, jitter=jitter, u_fine=u_fine)
+    assert out['visibility'].shape == (V, M, 1) and out['weights'].shape == (V, M, S + NI - 1, 1)
+    assert out['all_coords'].shape == (V, M, S + NI, 3) and out['feature_volume'].shape == (V, M, S + NI, 3)
+    for key, gk in (('visibility', 'visibility'), ('weights', 'weights'), ('all_coords', 'all_coords'), ('feature_volume', 'feature_volume')):
+        ref = torch.from_numpy(g[gk].astype(np.float32))
+        e = rel_l2(out[key].cpu(), ref)
+        print(tag, key, e)
+        assert e < 2e-3, (key, e)                                    # fp16-stored goldens for the per-sample tensors
+    img = out['feature_samples'].permute(0, 2, 1).reshape(V, 3, res, res)
+    assert rel_l2(img.cpu(), g['image_raw']) < 2e-3
+    # the merged weights sum to weights_samples, and visibility is what is left of the ray
+    assert torch.allclose(out['weights'].sum(2), out['weights_samples'], atol=2e-5)
+    assert torch.allclose(out['visibility'], 1 - out['weights_samples'], atol=2e-3)
+    # a ray LIST: drop 5 rays -> M - 5 (no res x res image behind it); per-ray reductions are unchanged, the call-wide ones
+    # (invalid-ray fix-up, depth clamp range) see fewer rays, so compare what does not depend on them
+    keep = torch.arange(M)[5:]
+    o2 = tp.renderer(pl, tp.decoder, ro[:, keep].contiguous(), rd[:, keep].contiguous(), tp.rendering_kwargs, False,
+                     jitter=jitter.reshape(V, M, S)[:, keep], u_fine=u_fine.reshape(V, M, NI)[:, keep].reshape(-1, NI))
+    assert o2['feature_samples'].shape == (V, M - 5, 3) and 'weights' not in o2
+    hit = (out['weights_samples'][:, keep] > 1e-3).squeeze(-1)        # rays that cross the box are untouched by the fix-up
+    assert hit.any()
+    assert torch.allclose(o2['feature_samples'][hit], out['feature_samples'][:, keep][hit], atol=1e-5)
+    assert torch.allclose(o2['visibility'][hit], out['visibility'][:, keep][hit], atol=1e-5)
+
+
+def test_generic_marcher_agrees_with_the_lane_per_sample_kernel(hip_lib):
+    """The Objaverse preset through both kernels of csrc/render.hip (return_meta selects the generic one): same images to fp32
+    summation-order differences."""
+    from oracle import render as orender
+    g, tp, opts, planes, cams, jitter, u_fine, (V, M, S, NI, res) = _preset_scene('objv64_meta')
+    ro, rd = (t.cuda() for t in orender.make_rays(cams, res))
+    pl = planes.cuda().view(V, 3, 32, 128, 128)
+    a = tp.renderer(pl, tp.decoder, ro, rd, tp.rendering_kwargs, False, jitter=jitter, u_fine=u_fine)
+    b = tp.renderer(pl, tp.decoder, ro, rd, tp.rendering_kwargs, True, jitter=jitter, u_fine=u_fine)
+    for k in ('feature_samples', 'depth_samples', 'weights_samples', 'visibility'):
+        e = rel_l2(b[k], a[k])
+        print('generic vs fast', k, e)
+        assert e < 2e-5, (k, e)
+    ss_a, ss_b = a['shape_synthesized'], b['shape_synthesized']
+    assert torch.allclose(ss_a['coarse_coords'], ss_b['coarse_coords'], atol=1e-6)
+    inb = ss_a['coarse_densities'] > -1e30
+    assert torch.equal(inb, ss_b['coarse_densities'] > -1e30) and rel_l2(ss_b['coarse_densities'][inb], ss_a['coarse_densities'][inb]) < 1e-5

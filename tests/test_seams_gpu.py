@@ -73,8 +73,9 @@ def test_integration_md_stub_renderer_and_explicit_rays(hip_lib):
         print('explicit rays', key, e)
         assert e < 1e-4, (key, e)                   # rays computed by two routes (in-kernel vs host fp32): not bit-identical
     ns = _stub_namespace()
-    f, d, w = ns['importance_renderer_forward'](planes.view(V, 3, 32, 128, 128), tp.decoder, ro, rd, rk, j, u)
-    assert torch.equal(f, out['feature_samples']) and torch.equal(d, out['depth_samples']) and torch.equal(w, out['weights_samples'])
+    st = ns['importance_renderer_forward'](planes.view(V, 3, 32, 128, 128), tp.decoder, ro, rd, rk, j, u)
+    for key in ('feature_samples', 'depth_samples', 'weights_samples', 'visibility'):
+        assert st[key].shape == out[key].shape and torch.equal(st[key], out[key]), key
 
 
 def test_sampling_details(hip_lib):
