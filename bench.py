@@ -149,8 +149,8 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * Nq * N * H * Dh_true * n_net     # 4*Nq*Nkv*(H*Dh) per sample-layer (algorithmic: the true head size)
     ach = flops / (ms * 1e-3) / 1e12
-    kres = (N % 256 == 0 and 512 <= N <= 768 and Nq % 256 == 0 and Dh == 64 and n_net * H >= 256 and os.environ.get('LN3D_ATTN_V') in (None, '', '4'))
-    stream = (N % 256 == 0 and Dh == 64 and not kres and os.environ.get('LN3D_ATTN_V') != '2')
+    kres = N % 256 == 0 and 512 <= N <= 768 and Nq % 256 == 0 and Dh == 64 and n_net * H >= 256
+    stream = N % 256 == 0 and Dh == 64 and not kres
     name = ("attn_kres_kernel (K resident in LDS, V^T ring, row sums on the matrix pipe)" if kres else
             "attn_stream_kernel (one workgroup per head, 8-slot LDS-DMA K/V ring)" if stream else "attn_kernel<%d, DT %d> (tiled ring kernel; %d-wide heads in %d-wide rows, the padding skipped)" % (Dh, Dh_true, Dh_true, Dh))
     traffic, src = pmc_traffic("attention_%dx%dx%dx%d" % (n_net * H, Nq, N, Dh))

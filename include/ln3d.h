@@ -25,8 +25,8 @@ extern "C" {
 
 const char* ln3d_strerror(int code);
 int ln3d_abi_version(void);
-/* The measurement switches (environment variables LN3D_GEMM_TILE, LN3D_GEMM_ABL, LN3D_ATTN_*) are read ONCE per
- * process, at the first launch that consults them.  A harness that changes them afterwards calls this to have them re-read. */
+/* The one measurement switch left in the library (environment variable LN3D_GEMM_TILE: force a tile configuration, swept by the tests)
+ * is read ONCE per process, at the first launch that consults it.  A harness that changes it afterwards calls this to have it re-read. */
 void ln3d_reload_env(void);
 
 /* ---------------------------------------------------------------- streams that own part of the chip (ABI 9)
@@ -96,31 +96,14 @@ typedef struct {
    *   identical (the zero embeddings of the unconditional CFG branch, sgm_DiffusionEngine.py:448-452): softmax over identical keys
    *   is uniform, so that sub-block is the constant to_out(v) + b per sample and layer, and its two GEMMs are skipped for them. */
   const float* res_bias; int64_t res_bias_ld;
-  /* ---- ABI 8: norm + modulate fused into the GEMMs on either side of it (dit/dit_models_xformers.py:306-323 norm1 / norm2 +
-   * modulate; the standalone ln3d_norm_modulate pass between a residual update and the next projection disappears).
-   * For y = norm(x) * (1 + s) + sh feeding out = y W^T + b, with per-row statistics mu_m, rs_m = rsqrt(var_m + eps):
-   *     out[m, n] = rs_m * ( sum_k W[n,k] x[m,k] (1 + s_k)  -  mu_m * u[n] ) + c[n],   u = W (1 + s),  c = W sh + b.
-   * PRODUCER side (LN3D_EPI_GATE_RES, full tiles, gate_rows >= 32): the bf16 copy out1 of the updated residual is multiplied by
-   * copy_scale[(m / gate_rows) * copy_scale_ld + n] (= 1 + s of the NEXT norm; rows >= copy_scale_rows stay plain copies) and
-   * row_stats_out [M, N / 64, 2] f32 receives (sum x, sum x^2) of every row over each 64-feature group, in a fixed order. */
-  const float* copy_scale; int64_t copy_scale_ld; int copy_scale_rows;
-  float* row_stats_out;
-  /* CONSUMER side (any epilogue of the large-tile kernels): row_stats [M, row_stats_parts, 2] of the activation rows (K = 64 *
-   * row_stats_parts), row_norm_kind 0 = LayerNorm (mean and variance), 1 = RMSNorm (mu = 0); col_u / col_c f32 rows indexed
-   * by (m / col_rows) * col_ld + n.  Applied to the fp32 accumulators before the epilogue proper; `bias` must be NULL (it is part
-   * of c).  NULL row_stats = off. */
-  const float* row_stats; int row_stats_parts; float row_eps; int row_norm_kind;
-  const float* col_u; const float* col_c; int64_t col_ld; int col_rows;
+  /* (ABI 8 carried arguments that fused LayerNorm / RMSNorm + modulate into the GEMMs around it; measured slower than the standalone
+   * norm kernel in situ - profiles/r4_gemm.md section 5 - and removed in ABI 9.) */
 } ln3d_gemm_args;
 
 int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream);
 /* 1 when ln3d_gemm_bf16's HEADS epilogue will apply head_norm0/1 itself for this problem (the tile the library picks is
  * head-aligned), 0 when the caller has to run ln3d_rmsnorm_heads_bf16 after the GEMM. */
 int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int head_dim_pad);
-/* 1 when ln3d_gemm_bf16 serves the fused-norm arguments (ABI 8) for an [M, N] problem; role 0 = consumer side (row_stats, col_u,
- * col_c; epilogues BF16 / GELU_ERF / HEADS), 1 = producer side (copy_scale, row_stats_out on GATE_RES: the tile the library
- * picks must divide M and N).  head_split: the consumer is a head-split projection (restricts the tile choice). */
-int ln3d_gemm_norm_fusable(int M, int N, int role, int head_split);
 
 /* ---------------------------------------------------------------- fused attention
  * O[b, q, h*Dh + d] = softmax_k(scale * Q.K^T) V, bf16 in/out, fp32 softmax, MFMA 32x32x16.

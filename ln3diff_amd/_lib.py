@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libln3d_hip.so")
 
 SYMBOLS = [
-    "ln3d_strerror", "ln3d_abi_version", "ln3d_reload_env", "ln3d_gemm_bf16", "ln3d_gemm_heads_norm_fusable", "ln3d_gemm_norm_fusable", "ln3d_attention_bf16",
+    "ln3d_strerror", "ln3d_abi_version", "ln3d_reload_env", "ln3d_gemm_bf16", "ln3d_gemm_heads_norm_fusable", "ln3d_attention_bf16",
     "ln3d_rmsnorm_heads_bf16", "ln3d_norm_modulate", "ln3d_timestep_embedding",
     "ln3d_add_act_cast", "ln3d_cast_f32_bf16", "ln3d_patch_embed", "ln3d_final_layer",
     "ln3d_edm_euler_step", "ln3d_ddpm_step", "ln3d_flow_euler_step", "ln3d_axpby",
@@ -33,10 +33,7 @@ class GemmArgs(C.Structure):
                 ("tokens", i32), ("tok_pad", i32), ("heads", i32), ("head_dim", i32),
                 ("transpose_mask", i32), ("ctx_keys", i32), ("ctx_pad", i32), ("ctx_scale", f32), ("head_dim_pad", i32),
                 ("head_norm0", vp), ("head_norm1", vp), ("head_norm_eps", f32),
-                ("res_bias", vp), ("res_bias_ld", i64),
-                ("copy_scale", vp), ("copy_scale_ld", i64), ("copy_scale_rows", i32), ("row_stats_out", vp),
-                ("row_stats", vp), ("row_stats_parts", i32), ("row_eps", f32), ("row_norm_kind", i32),
-                ("col_u", vp), ("col_c", vp), ("col_ld", i64), ("col_rows", i32)]
+                ("res_bias", vp), ("res_bias_ld", i64)]
 
 
 class AttnArgs(C.Structure):

@@ -1243,38 +1243,14 @@ __global__ __launch_bounds__(256, 3) void attn_short_kernel(AttnP p) {
   }
 }
 
-// Measurement switches (environment, read ONCE per process; every setting runs HIP kernels of this file):
-//   LN3D_ATTN_V     2 = attn_kernel (r1 ring) for every shape, 3 = attn_stream_kernel where it applies, 4 / unset = default choice
-//   LN3D_ATTN_KRES  bit 0: static priority for waves 4-7, bit 1: count the O stores in the vmcnt waits (default 1)
-//   LN3D_ATTN_SHORT 1 = short-sequence kernel for non-causal Nk <= 128 too;  LN3D_ATTN_QT 2 = two query tiles per wave there
-//   LN3D_ATTN_SPLIT workgroups per (batch, head) of the streaming kernels
-struct AttnCfg { int ver, kres, force_short, qt, split; };
-static AttnCfg g_attn_cfg = {-1, 1, 0, 1, 0};
-static const AttnCfg& attn_cfg() {
-  if (g_attn_cfg.ver < 0) {
-    const char* e;
-    AttnCfg c = {0, 1, 0, 1, 0};
-    if ((e = getenv("LN3D_ATTN_V")) != nullptr) c.ver = atoi(e);
-    if ((e = getenv("LN3D_ATTN_KRES")) != nullptr) c.kres = atoi(e) & 3;
-    if ((e = getenv("LN3D_ATTN_SHORT")) != nullptr) c.force_short = e[0] == '1';
-    if ((e = getenv("LN3D_ATTN_QT")) != nullptr) c.qt = e[0] == '2' ? 2 : 1;
-    if ((e = getenv("LN3D_ATTN_SPLIT")) != nullptr) c.split = atoi(e);
-    if (c.ver < 0) c.ver = 0;
-    g_attn_cfg = c;
-  }
-  return g_attn_cfg;
-}
-
-extern "C" void ln3d_attn_reload_env(void) { g_attn_cfg.ver = -1; }
+// r5: the attention kernels have no environment switches left - one kernel per shape class (the r1 - r4 A/B switches LN3D_ATTN_V /
+// _KRES / _SHORT / _QT / _SPLIT and the instantiations they selected are gone; their measurements are in profiles/r2 - r4_attn*.md).
+extern "C" void ln3d_attn_reload_env(void) {}
 
 static int launch_attn_short(const AttnP& p, hipStream_t s) {
   // one query tile per wave (128 queries per workgroup): twice the workgroups, so load, compute and store phases of
-  // different workgroups overlap on a CU (the kernel is a latency-bound stream of Q in / O out); LN3D_ATTN_QT=2 for A/B runs
-  if (attn_cfg().qt == 2) {
-    hipLaunchKernelGGL(attn_short_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.H), dim3(256), 2 * (KVB * 128 + 64 * 128) + 4 * 4096, s, p);
-  } else {
-    hipLaunchKernelGGL(attn_short_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.H), dim3(256), 2 * (KVB * 128 + 64 * 128) + 4 * 4096, s, p);
-  }
+  // different workgroups overlap on a CU (the kernel is a latency-bound stream of Q in / O out)
+  hipLaunchKernelGGL(attn_short_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.H), dim3(256), 2 * (KVB * 128 + 64 * 128) + 4 * 4096, s, p);
   return ln3d_check_launch();
 }
 
@@ -1303,7 +1279,6 @@ static int launch_attn_stream(AttnP p, hipStream_t s) {
   const int nqb = (p.Nq + 255) / 256, BH = p.B * p.H, cus = ln3d_stream_cus(s);
   int nsplit = 1;
   if (BH < cus) { nsplit = (cus + BH - 1) / BH; if (nsplit > nqb) nsplit = nqb; }
-  if (attn_cfg().split > 0) { nsplit = attn_cfg().split; if (nsplit > nqb) nsplit = nqb; }
   p.nsplit = nsplit;
   hipLaunchKernelGGL(attn_stream_kernel, dim3(BH * nsplit), dim3(512), LDS, s, p);
   return ln3d_check_launch();
@@ -1321,12 +1296,7 @@ static int launch_attn_kres_t(const AttnP& p, hipStream_t s) {
 }
 static int launch_attn_kres(AttnP p, hipStream_t s) {
   p.nsplit = 1;                                            // every workgroup walks all query blocks of its head: K is fetched once
-  switch (attn_cfg().kres) {
-    case 0: return launch_attn_kres_t<false, false>(p, s);
-    case 1: return launch_attn_kres_t<true, false>(p, s);
-    case 2: return launch_attn_kres_t<false, true>(p, s);
-    default: return launch_attn_kres_t<true, true>(p, s);
-  }
+  return launch_attn_kres_t<true, false>(p, s);            // static priority for waves 4-7, O stores not counted in the vmcnt waits (r3 A/B)
 }
 
 extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
@@ -1346,13 +1316,12 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   if (a->Dh == 64) {
     // The short-sequence kernel serves the causal text tower; for the non-causal 77-key cross-attention it measures 2 us
     // faster in isolation but slower inside the sampling loop than the ring kernel (and the DiT runs that attention inside
-    // the query-projection GEMM anyway, LN3D_EPI_CROSS_ATTN), so it is opt-in there: LN3D_ATTN_SHORT=1.
-    const AttnCfg& cfg = attn_cfg();
-    if (a->Nk <= 128 && (a->causal || cfg.force_short)) return launch_attn_short(p, s);
-    if ((a->Nk & 255) == 0 && a->Nk_pad == a->Nk && cfg.ver != 2) {
+    // the query-projection GEMM anyway, LN3D_EPI_CROSS_ATTN), so the ring kernel serves it.
+    if (a->Nk <= 128 && a->causal) return launch_attn_short(p, s);
+    if ((a->Nk & 255) == 0 && a->Nk_pad == a->Nk) {
       // K-resident kernel: K of a head fits beside the V^T ring (Nk <= 768) and there is a head for every CU, so that one
       // workgroup per head walks all its query blocks (fewer heads: the query blocks of a head are shared out - attn_stream)
-      if (cfg.ver != 3 && a->Nk >= 512 && a->Nk <= 768 && (a->Nq & 255) == 0 && a->Nq_pad == a->Nq && p.B * p.H >= ln3d_stream_cus(s))
+      if (a->Nk >= 512 && a->Nk <= 768 && (a->Nq & 255) == 0 && a->Nq_pad == a->Nq && p.B * p.H >= ln3d_stream_cus(s))
         return launch_attn_kres(p, s);
       return launch_attn_stream(p, s);
     }

@@ -39,10 +39,6 @@ struct GemmP {
   int ctx_keys, ctx_pad; float ctx_scale_log2;
   const float* hn0; const float* hn1; float hn_eps;   // HEADS: fused qk_norm weights (outputs 0 / 1) or NULL
   const float* rb; int64_t rb_ld;                      // GATE_RES: per-sample row added after gating (sample = row / gate_rows) or NULL
-  // norm + modulate fused into the GEMMs around it (include/ln3d.h, ABI 8)
-  const float* cs; int64_t cs_ld; int cs_rows; float* st_out;           // producer (GATE_RES): out1 = bf16(x * cs), (sum, sum^2) partials
-  const float* st_in; int st_parts; float st_eps; int st_kind;          // consumer: row statistics of the activation rows
-  const float* cu; const float* ccv; int64_t c_ld; int c_rows;          // consumer: u = W (1 + s), c = W sh + b rows
 };
 
 template <int EPI>
@@ -228,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 // everything that depends on fb (bias, head / dim split) or on the run's first token (sample index, gate rows, base
 // pointers) is computed once per run instead of once per store: the head-split epilogue spent more time in integer
 // divisions and 64-bit multiplies than in stores before this.
-template <int EPI, bool FN = false>      // FN: the fused-norm producer side (copy scale, row statistics)
+template <int EPI>
 struct RunEpi {
   float4 bias;
   bool generic;            // a sample shorter than the run (or a transposed target): per-element path
@@ -237,7 +233,6 @@ struct RunEpi {
   // GATE_RES
   float4 g0, g1; int grows_left;
   float4 r0, r1;            // res_bias rows of the run's first sample / the next one
-  float4 c0;                // copy_scale row (1 + s of the next norm; shared by all samples)
 
   __device__ __forceinline__ void init_feature(const GemmP& p, int fb, int& which, int& h, int& d) const {
     const int dm = p.heads * p.head_dim;
@@ -260,9 +255,8 @@ struct RunEpi {
     if constexpr (EPI == LN3D_EPI_GATE_RES) {
       g0 = g1 = make_float4(1.f, 1.f, 1.f, 1.f);
       r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      c0 = make_float4(1.f, 1.f, 1.f, 1.f);
       grows_left = 1 << 30;
-      if (p.gate || p.rb || (FN && p.cs)) {
+      if (p.gate || p.rb) {
         generic = p.gate_rows < 32;
         const int s0 = tb / p.gate_rows;
         grows_left = p.gate_rows - (tb - s0 * p.gate_rows);
@@ -275,9 +269,6 @@ struct RunEpi {
           r0 = *reinterpret_cast<const float4*>(p.rb + (int64_t)s0 * p.rb_ld + fb);
           if (two) r1 = *reinterpret_cast<const float4*>(p.rb + (int64_t)(s0 + 1) * p.rb_ld + fb);
         }
-        if constexpr (FN) {
-          if (p.cs) c0 = *reinterpret_cast<const float4*>(p.cs + fb);                // one row for every sample (copy_scale_ld == 0, host-checked)
-        }
       }
     }
   }
@@ -288,21 +279,8 @@ struct RunEpi {
     x.x += (v.x + bias.x) * g.x + r.x; x.y += (v.y + bias.y) * g.y + r.y; x.z += (v.z + bias.z) * g.z + r.z; x.w += (v.w + bias.w) * g.w + r.w;
     *reinterpret_cast<float4*>((float*)p.out0 + (int64_t)(tb + row) * p.ldo + fb) = x;
     if (p.out1) {
-      uint2 o;
-      if constexpr (FN) {
-        // r4: the copy can carry the NEXT norm's modulation (x * (1 + s)); rows from copy_scale_rows on stay plain copies
-        const float4 cm = (tb + row >= p.cs_rows) ? make_float4(1.f, 1.f, 1.f, 1.f) : c0;
-        o.x = pack2bf(x.x * cm.x, x.y * cm.y); o.y = pack2bf(x.z * cm.z, x.w * cm.w);
-      } else { o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w); }
+      uint2 o; o.x = pack2bf(x.x, x.y); o.y = pack2bf(x.z, x.w);
       *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (int64_t)(tb + row) * p.ldo + fb) = o;
-    }
-    if (FN && p.st_out) {
-      // (sum x, sum x^2) of this row over the wave's 64 features: the 16 lanes of a DPP row hold them (4 each); fixed order
-      float s1 = (x.x + x.y) + (x.z + x.w), s2 = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-      s1 = dpp_add_step<0x111, 0xf>(s1); s1 = dpp_add_step<0x112, 0xf>(s1); s1 = dpp_add_step<0x114, 0xf>(s1); s1 = dpp_add_step<0x118, 0xf>(s1);
-      s2 = dpp_add_step<0x111, 0xf>(s2); s2 = dpp_add_step<0x112, 0xf>(s2); s2 = dpp_add_step<0x114, 0xf>(s2); s2 = dpp_add_step<0x118, 0xf>(s2);
-      if ((threadIdx.x & 15) == 15)
-        *reinterpret_cast<float2*>(p.st_out + ((int64_t)(tb + row) * (p.N >> 6) + (fb >> 6)) * 2) = make_float2(s1, s2);
     }
   }
   __device__ __forceinline__ void apply(const GemmP& p, int tb, int row, int fb, float4 v) const {
@@ -342,7 +320,7 @@ struct RunEpi {
   }
 };
 
-template <int EPI, int NI, int NJ, bool DBUF = true, bool FN = false>
+template <int EPI, int NI, int NJ, bool DBUF = true>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
   constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
   constexpr bool kBf16Out = kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_CROSS_ATTN;
@@ -381,7 +359,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
       // sit in conditionals) then covers only the previous batch, which the block being stored needs anyway
       auto blk_fb = [&](int blk) __attribute__((always_inline)) { return fw0 + (blk / NJ) * 64 + 4 * rc; };
       auto blk_tb = [&](int blk) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tw0 + (blk % NJ) * 32); };
-      RunEpi<EPI, FN> re_cur, re_nxt;
+      RunEpi<EPI> re_cur, re_nxt;
       re_cur.init(p, blk_fb(0), blk_tb(0), 0, 0, 0);
       fetch(0, xres[0]);
 #pragma unroll
@@ -418,7 +396,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
   for (int ih = 0; ih < NI / 2; ++ih) {
     const int fb = fw0 + ih * 64 + 4 * rc;
     const bool fok = fb < p.N;
-    RunEpi<EPI, FN> re;
+    RunEpi<EPI> re;
     int which = 0, h = 0, d = 0;
     if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
     float4 wb0 = make_float4(0.f, 0.f, 0.f, 0.f), wb1 = wb0;
@@ -537,7 +515,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
     const int r8 = lane >> 3, c8 = lane & 7;
     const int fb = fw0 + i * 32 + 4 * c8;
     const bool fok = fb < p.N;
-    RunEpi<EPI, FN> re;
+    RunEpi<EPI> re;
     int which = 0, h = 0, d = 0;
     if constexpr (EPI == LN3D_EPI_HEADS) { if (fok) re.init_feature(p, fb, which, h, d); }
     float4 pre_bias[4];
@@ -599,7 +577,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
 //  * Workgroup -> tile map is XCD-aware (block b runs on XCD b % 8): an XCD owns ntt/8 token panels and walks the
 //    feature tiles in groups of 4, so concurrently running tiles share 4 W panels and its own X panels.
 //  * Epilogue through LDS (staged_epilogue) except V^T tiles.
-template <int EPI, int NW, int WGT, int NI, int NJ, int FN = 0>     // FN: fused norm, 1 = consumer side, 2 = producer side (GATE_RES)
+template <int EPI, int NW, int WGT, int NI, int NJ>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) void gemm_bf16_ring64_kernel(GemmP p) {
   constexpr int WGF = NW / WGT, BF = 32 * NI * WGF, BT = 32 * NJ * WGT;
   constexpr int WB = BF * 128, STAGEB = (BF + BT) * 128, NPW = (BF + BT) / 8 / NW;
@@ -675,15 +653,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   bf16x8 a0[NI], b0[NJ], a1[NI], b1[NJ];
   const int ns = (ABL & 2) ? 2 : p.K / 64;
 
-  // r4 fused norm, consumer side (FN == 1): the wave's slice of the u / c rows goes into 1 KB of LDS above the ring by ONE
-  // LDS-DMA instruction issued AHEAD of stage 0's (vmcnt counts in order: the stage-0 wait covers it); the row statistics
-  // are read behind the K loop.
-  float rsc[NJ], rmu[NJ];                         // rs_m and rs_m * mu_m of the lane's token in every token block
-  int64_t crow[NJ];
-  constexpr int UCB = 2 * STAGEB;                 // u / c slices: wave w at UCB + w * 1024, u quads first, then c quads
-  constexpr int STB = UCB + NW * 1024;            // the tile's row-statistics partials, BT rows of st_parts float2
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) { rsc[j] = 1.f; rmu[j] = 0.f; crow[j] = 0; }
   // CROSS_ATTN: the K rows of this tile's sample and 4 heads go into the LDS above the ring now (40 KB at 77 keys), long
   // before the epilogue needs them.  Row r of head hh at XK + hh*XKH + r*128, 16-byte chunk c at c ^ ((r >> 1) & 7).
   constexpr int XK = 2 * STAGEB, XKH = 96 * 128;
@@ -700,29 +669,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     }
   }
 
-  if (FN == 1 && p.st_in) {
-    {
-      // the tile's BT rows of (sum, sum^2) partials are ONE contiguous piece of st_in: copied 1 KB per instruction (ragged last
-      // tile: chunks past row M - 1 re-read its last chunk; those tokens are never stored)
-      const int rowb = p.st_parts * 8, tot = BT * rowb;
-      const char* g0 = reinterpret_cast<const char*>(p.st_in) + (int64_t)t0 * rowb;
-      const int lim = (p.M - t0) * rowb - 16;
-      for (int o = wid * 1024; o < tot; o += NW * 1024) {
-        const int off = min(o + lane * 16, lim);
-        lds_dma16_v(g0 + off, lds_addr(smem) + STB + o);
-      }
-    }
-    if (p.c_ld == 0) {
-      constexpr int NQ = 8 * NI;                  // float4 quads of one vector in the wave's 32 * NI features
-      const int q_ = lane % NQ, wh_ = (lane / NQ) & 1;
-      int fq_ = f0 + wf * 32 * NI + 4 * q_; fq_ = fq_ < p.N ? fq_ : 0;
-      lds_dma16_v((wh_ ? p.ccv : p.cu) + fq_, lds_addr(smem) + UCB + wid * 1024);     // lane l lands at + 16 l: u quads, then c quads
-    }
-  }
 #pragma unroll
   for (int q = 0; q < NPW; ++q) Y_ISSUE1(0, q);
   if (ns > 1) { _Pragma("unroll") for (int q = 0; q < NPW; ++q) Y_ISSUE1(1, q); }
-  if (ns > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); }          // stage 0 (and the older u / c slice) landed
+  if (ns > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); }          // stage 0 landed
   else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -806,76 +756,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   Y_STAGE(s, false, false, false);
 
   if constexpr ((ABL & 1) != 0) { if (acc[0][0][0] != 12345.f) return; }
-  // r4: the norm that produced this GEMM's activations, applied to the accumulators (include/ln3d.h, ABI 8): the rows arrived as
-  // bf16(x * (1 + s)); out = rs_m * (acc - mu_m * u[n]) + c[n] with (mu_m, rs_m) from the producer's (sum, sum^2) partials.
-  if (FN == 1 && p.st_in) {
-    // the row statistics: the partials of the tile's tokens sit in LDS since the prologue (as global loads behind the K loop,
-    // or in front of it where hipcc's waits for them also drained the operand DMAs, they cost the fc1 GEMM +17 us)
-    const float invk = 1.0f / (float)p.K;
-    // partials are read as float4 = two 64-feature groups; the two lanes of a token (lane, lane ^ 32) sum half of them each.
-    // Rows of 128 bytes put every other token on the same banks: the lanes start at rotated chunks then.
-    constexpr int MAXH = 5;                       // K <= 1280
-    const int np4 = p.st_parts >> 1, hp4 = (np4 + 1) >> 1;
-    const int rot = ((hp4 & (hp4 - 1)) == 0 && (np4 & 1) == 0) ? hp4 - 1 : 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int trow = wt * 32 * NJ + 32 * j + l31;
-      int tok = t0 + trow; tok = tok < p.M ? tok : p.M - 1;
-      const float4* sp = reinterpret_cast<const float4*>(smem + STB + trow * p.st_parts * 8) + hi * hp4;
-      const int cnt = min(hp4, np4 - hi * hp4);
-      float4 t[MAXH];
-#pragma unroll
-      for (int k = 0; k < MAXH; ++k) t[k] = sp[k < cnt ? (rot ? ((k + l31) & rot) : k) : 0];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < MAXH; ++k) {
-        const float w_ = k < cnt ? 1.0f : 0.0f;
-        s1 = fmaf(w_, t[k].x + t[k].z, s1); s2 = fmaf(w_, t[k].y + t[k].w, s2);
-      }
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      const float mean = p.st_kind == 0 ? s1 * invk : 0.f;
-      const float var = fmaxf(s2 * invk - mean * mean, 0.f);
-      rsc[j] = rsqrtf(var + p.st_eps); rmu[j] = rsc[j] * mean;
-      crow[j] = (int64_t)(tok / p.c_rows) * p.c_ld;
-    }
-    // u / c rows: one row for every sample (c_ld == 0: the samplers of this path share the timestep) is read once per feature
-    // quad; per-sample rows are read per (quad, token block)
-#define Y_AFF(i, j, g, U, C)                                                                              \
-    {                                                                                                     \
-      const float a_ = rsc[j], b_ = rmu[j];                                                               \
-      acc[i][j][4 * (g) + 0] = fmaf(a_, acc[i][j][4 * (g) + 0], fmaf(-b_, (U).x, (C).x));                 \
-      acc[i][j][4 * (g) + 1] = fmaf(a_, acc[i][j][4 * (g) + 1], fmaf(-b_, (U).y, (C).y));                 \
-      acc[i][j][4 * (g) + 2] = fmaf(a_, acc[i][j][4 * (g) + 2], fmaf(-b_, (U).z, (C).z));                 \
-      acc[i][j][4 * (g) + 3] = fmaf(a_, acc[i][j][4 * (g) + 3], fmaf(-b_, (U).w, (C).w));                 \
-    }
-    const int fq0 = f0 + wf * 32 * NI + 4 * hi;
-    if (p.c_ld == 0) {
-      const char* ucl = smem + UCB + wid * 1024;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        __builtin_amdgcn_sched_barrier(0);        // one feature block (4 quads of u and of c from LDS) at a time
-        const float4* pu = reinterpret_cast<const float4*>(ucl) + 8 * i + hi;
-        const float4* pc = pu + 8 * NI;
-        const float4 ua = pu[0], ub = pu[2], uc_ = pu[4], ud = pu[6];
-        const float4 ca = pc[0], cb = pc[2], cc_ = pc[4], cd = pc[6];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) { Y_AFF(i, j, 0, ua, ca); Y_AFF(i, j, 1, ub, cb); Y_AFF(i, j, 2, uc_, cc_); Y_AFF(i, j, 3, ud, cd); }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const float4 uu = *reinterpret_cast<const float4*>(p.cu + crow[j] + fq0 + i * 32 + 8 * g);
-            const float4 cv = *reinterpret_cast<const float4*>(p.ccv + crow[j] + fq0 + i * 32 + 8 * g);
-            Y_AFF(i, j, g, uu, cv);
-          }
-        }
-    }
-  }
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) {
     // acc[i][j] = q^T of head (f0/64 + wf): features (rows) x the wave's 96 tokens (columns, lane & 31 within block j).
     // Same swapped products and lane-local softmax as csrc/attention.hip; q is consumed straight from the accumulators
@@ -1099,26 +979,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     return;
   }
   __builtin_amdgcn_s_barrier();
-  staged_epilogue<EPI, NI, NJ, (NW <= 8), FN == 2>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
+  staged_epilogue<EPI, NI, NJ, (NW <= 8)>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
 }
 
-template <int EPI, int NW, int WGT, int NI, int NJ, int FN = 0>
+template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
-  constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? (NW / WGT) * 96 * 128 : 0) + (FN == 1 ? NW * 1024 : 0);
+  constexpr int LDSB = 2 * (BF + BT) * 128 + (EPI == LN3D_EPI_CROSS_ATTN ? (NW / WGT) * 96 * 128 : 0);
   static_assert(2 * (BF + BT) * 128 >= NW * 8192 && LDSB <= 163840, "staging regions live in the ring");
   static AttrOnce attr_once;
   if (attr_once.need()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ, FN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FN == 1 ? 163840 : LDSB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
   }
   const int nft = (p.N + BF - 1) / BF, ntt = (p.M + BT - 1) / BT;
-  int ldsb = LDSB;
-  if (FN == 1 && p.st_in) {                       // + the tile's row-statistics partials
-    ldsb += BT * p.st_parts * 8;
-    if (ldsb > 163840) return LN3D_ERR_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL((gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ, FN>), dim3(nft * ntt), dim3(NW * 64), ldsb, s, p);
+  hipLaunchKernelGGL((gemm_bf16_ring64_kernel<EPI, NW, WGT, NI, NJ>), dim3(nft * ntt), dim3(NW * 64), LDSB, s, p);
   return ln3d_check_launch();
 }
 
@@ -1150,22 +1025,6 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
   }
 }
 
-
-// Fused-norm variants (ABI 8: row statistics / copy scale on the producer side, the row affine on the consumer side) are separate
-// instantiations, for the epilogues and tiles the DiT blocks use them with: the extra live values cost the plain kernels
-// registers otherwise (the 12-wave tile spilled inside its K loop with them compiled in).
-template <int EPI>
-static int run_cfg_fused(const GemmP& p, hipStream_t s, int cfg) {
-  if constexpr (EPI == LN3D_EPI_GATE_RES || EPI == LN3D_EPI_HEADS || EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_BF16) {
-    constexpr int FN = EPI == LN3D_EPI_GATE_RES ? 2 : 1;
-    switch (cfg) {
-      case 7: if constexpr (FN == 2) return launch_ring64<EPI, 8, 4, 4, 2, FN>(p, s); else return LN3D_ERR_UNSUPPORTED;
-      case 9: return launch_ring64<EPI, 8, 2, 2, 3, FN>(p, s);
-      case 14: if constexpr (EPI == LN3D_EPI_GATE_RES) return launch_ring64<EPI, 4, 2, 2, 3, FN>(p, s); else return LN3D_ERR_UNSUPPORTED;
-      default: return LN3D_ERR_UNSUPPORTED;
-    }
-  } else return LN3D_ERR_UNSUPPORTED;
-}
 
 // Tile selection.  Small problems (per-sample adaLN / timestep GEMMs, the conv decoder's 32/64 channels) take the 128x128
 // kernel.  Otherwise the ring configuration with the least estimated time: rounds of one tile per CU x tile area / relative
@@ -1214,17 +1073,6 @@ extern "C" int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_d
   return (cfg == 8 || cfg == 9 || cfg == 12 || cfg == 14) ? 1 : 0;
 }
 
-// 1 when the fused-norm arguments (ABI 8) are served for an [M, N] problem: role 0 = consumer (row_stats / col_u / col_c),
-// 1 = producer (copy_scale / row_stats_out on LN3D_EPI_GATE_RES: full tiles of the configuration the library picks)
-extern "C" int ln3d_gemm_norm_fusable(int M, int N, int role, int head_split) {
-  int cfg = pick_cfg(M, N, head_split != 0);
-  if (cfg == 12 || cfg == 8) cfg = 9;
-  static const int BFT[15][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {256, 256}, {128, 384}, {256, 192}, {0, 0}, {0, 0}, {384, 192}, {0, 0}, {128, 192}};
-  if (role == 0) return (cfg == 7 || cfg == 9) ? 1 : 0;               // runs on the 256x192 tile either way
-  if (!(cfg == 7 || cfg == 9 || cfg == 14)) return 0;
-  return ((N % BFT[cfg][0]) == 0 && (M % BFT[cfg][1]) == 0 && (N % 64) == 0) ? 1 : 0;
-}
-
 extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   if (!a || !a->X || !a->W || !a->out0) return LN3D_ERR_BAD_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0 || (a->N % 4) != 0) return LN3D_ERR_BAD_ARG;
@@ -1248,23 +1096,6 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   p.ctx_keys = a->ctx_keys; p.ctx_pad = a->ctx_pad; p.ctx_scale_log2 = a->ctx_scale * 1.4426950408889634f;
   p.hn0 = a->head_norm0; p.hn1 = a->head_norm1; p.hn_eps = a->head_norm_eps;
   p.rb = a->epilogue == LN3D_EPI_GATE_RES ? a->res_bias : nullptr; p.rb_ld = a->res_bias_ld;
-  const bool is_gr = a->epilogue == LN3D_EPI_GATE_RES;
-  p.cs = is_gr ? a->copy_scale : nullptr; p.cs_ld = a->copy_scale_ld; p.cs_rows = a->copy_scale_rows;
-  p.st_out = is_gr ? a->row_stats_out : nullptr;
-  p.st_in = a->row_stats; p.st_parts = a->row_stats_parts; p.st_eps = a->row_eps; p.st_kind = a->row_norm_kind;
-  p.cu = a->col_u; p.ccv = a->col_c; p.c_ld = a->col_ld; p.c_rows = a->col_rows > 0 ? a->col_rows : 1;
-  // fused-norm arguments (ABI 8): validated here, served by the large-tile kernels only
-  if (p.st_in) {
-    if (!a->col_u || !a->col_c || a->bias || a->row_stats_parts * 64 != a->K || (a->row_stats_parts & 1) != 0 || a->row_stats_parts > 20 ||
-        ((uintptr_t)a->row_stats & 15) != 0 || (a->col_ld % 4) != 0 || ((uintptr_t)a->col_u & 15) != 0 ||
-        ((uintptr_t)a->col_c & 15) != 0 || ((uintptr_t)a->row_stats & 7) != 0 || a->epilogue == LN3D_EPI_CROSS_ATTN)
-      return LN3D_ERR_BAD_ARG;
-  }
-  if (p.cs || p.st_out) {
-    if (!is_gr || (p.cs && (!a->out1 || (a->copy_scale_ld % 4) != 0 || ((uintptr_t)a->copy_scale & 15) != 0)) || a->gate_rows < 32 || (a->N % 64) != 0 ||
-        (p.st_out && ((uintptr_t)a->row_stats_out & 7) != 0))
-      return LN3D_ERR_BAD_ARG;
-  }
   hipStream_t s = (hipStream_t)stream;
   // head split: the tiles whose wave row is 64 features (NI = 2) have the staged, head-aware epilogue (any head size that is a
   // multiple of 8 with heads * head_dim a multiple of 64)
@@ -1272,23 +1103,6 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
                            ((a->heads * a->head_dim) & 63) == 0 && a->tokens > 0 && (a->tokens & 31) == 0 && (a->M % a->tokens) == 0 &&
                            (a->N % 64) == 0;
   const int cfg = pick_cfg(a->M, a->N, head_staged, s);
-  if (p.st_in || p.cs || p.st_out) {
-    int fc = cfg == 12 || cfg == 8 ? 9 : cfg;                          // the fused variants exist for the 256x256 / 256x192 / 128x192 tiles
-    static const int BFT[15][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {256, 256}, {128, 384}, {256, 192}, {0, 0}, {0, 0}, {384, 192}, {0, 0}, {128, 192}};
-    if (fc != 7 && fc != 9 && fc != 14) return LN3D_ERR_UNSUPPORTED;   // the small-problem kernel has neither side
-    if (p.st_in && fc == 7) fc = 9;                                    // consumer: the tile's statistics partials need LDS the 256x256 ring lacks
-    if ((p.cs || p.st_out) && ((a->N % BFT[fc][0]) != 0 || (a->M % BFT[fc][1]) != 0 || a->copy_scale_ld != 0)) return LN3D_ERR_UNSUPPORTED;   // full tiles, one scale row
-    if (a->epilogue == LN3D_EPI_GATE_RES && p.st_in) return LN3D_ERR_UNSUPPORTED;     // a gate/residual GEMM is a producer only
-    switch (a->epilogue) {
-      case LN3D_EPI_GATE_RES: return run_cfg_fused<LN3D_EPI_GATE_RES>(p, s, fc);
-      case LN3D_EPI_HEADS:
-        if (a->tokens <= 0 || a->heads <= 0 || a->head_dim <= 0 || (a->head_dim % 4) != 0 || a->tok_pad < a->tokens || !head_staged) return LN3D_ERR_BAD_ARG;
-        return run_cfg_fused<LN3D_EPI_HEADS>(p, s, fc);
-      case LN3D_EPI_GELU_ERF: return run_cfg_fused<LN3D_EPI_GELU_ERF>(p, s, fc);
-      case LN3D_EPI_BF16: return run_cfg_fused<LN3D_EPI_BF16>(p, s, fc);
-      default: return LN3D_ERR_UNSUPPORTED;
-    }
-  }
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);
     case LN3D_EPI_BF16: return run_cfg<LN3D_EPI_BF16>(p, s, cfg);

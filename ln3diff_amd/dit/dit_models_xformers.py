@@ -245,7 +245,7 @@ def pad_head_columns(w, H, Dh):
     return out.reshape(w.shape[0], H * Dp)
 
 
-def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=None, nq=None, norm_kw=None):
+def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=None, nq=None):
     """h [B*N, D] bf16 -> attention output bf16 [B*nq, H*attn_out_dim] (nq <= N query rows kept).  For head sizes other than
     64/128 the QKV epilogue writes into 128-wide zero-initialised heads (exact: the extra dims contribute 0 to q.k); the kernel
     skips the padding for the sizes it knows (DiT-XL/2's 72: compact output, unpadded proj weight), otherwise it produces 0 output
@@ -260,9 +260,8 @@ def self_attention_hip(ws, tag, h_bf16, B, N, D, H, qkv_w, qkv_b, qn=None, kn=No
     Do = attn_out_dim(Dh)
     o = ws.get(tag + 'o', (B * nq, H * Do), torch.bfloat16)
     fused = qn is not None and ops.heads_norm_fusable(B * N, qkv_w.shape[0], N, Dh, Dp)
-    # norm_kw: the pre-norm of this projection applied inside the GEMM (ABI 8: row_stats / col_u / col_c; the bias is part of col_c)
-    ops.gemm(h_bf16, qkv_w, None if norm_kw else qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
-             transpose_mask=0b100, head_dim_pad=Dp, head_norm0=qn if fused else None, head_norm1=kn if fused else None, **(norm_kw or {}))
+    ops.gemm(h_bf16, qkv_w, qkv_b, ops.EPI_HEADS, q, k, vt, M=B * N, tokens=N, tok_pad=npad, heads=H, head_dim=Dh,
+             transpose_mask=0b100, head_dim_pad=Dp, head_norm0=qn if fused else None, head_norm1=kn if fused else None)
     if qn is not None and not fused:
         ops.rmsnorm_heads(q, qn, B * H * npad, Dp, true_dim=Dh)      # qn / kn: [Dp] (zero beyond Dh when padded)
         ops.rmsnorm_heads(k, kn, B * H * npad, Dp, true_dim=Dh)

@@ -26,11 +26,6 @@ from .dit_models_xformers import (CaptionEmbedder, DiTBlock, FinalLayer, PatchEm
                                   get_2d_sincos_pos_embed, self_attention_hip, pad_head_columns)
 
 
-def NORM_FUSE():
-    """Opt-in switch of the fused norm + modulate path (measured slower than the standalone norm kernel in situ, kept for its tests)."""
-    return os.environ.get('LN3D_NORM_FUSE', '0') not in ('', '0')
-
-
 class DiT(nn.Module):
     """Base container (reference dit/dit_models_xformers.py:681-835)."""
 
@@ -242,52 +237,7 @@ class DiT_TriLatent(DiT):
             return None
         mod_all = self._ws.get('mod_all', (n * rows, nmod), torch.float32)
         self._modulation(t_table[:, :rows].reshape(-1).to(dev), mod_all, 'ma')
-        cache = {'mod': mod_all, 'rows': rows}
-        if rows == 1 and NORM_FUSE():
-            cache.update(self._norm_fusion_tables(mod_all, n))
-        return cache
-
-    def _norm_fusion_tables(self, mod_all, n):
-        """r4, OPT-IN (LN3D_NORM_FUSE=1): LayerNorm + modulate of every block runs INSIDE the GEMMs around it (include/ln3d.h, ABI 8) - the residual-update
-        epilogue emits bf16(x * (1 + s)) and the row's (sum, sum^2) partials, the consuming projection applies
-            out = rs_m * (acc - mu_m * u[n]) + c[n],   u = W (1 + s),   c = W sh + b.
-        u and c depend on the step only (every sample of a step shares its timestep): evaluated here for the whole schedule, per
-        layer, with the operands split into bf16 hi + lo parts so that they carry fp32 accuracy (they multiply the row mean).
-        Returns {'cs': [n, depth, 2, D] (1 + s of norm1 / norm2), 'uc': [n, depth, 14 D] = [u_qkv | c_qkv | u_fc1 | c_fc1]}; None
-        entries (and the standalone norm kernels) when the tables would not fit MODCACHE_MAX_BYTES."""
-        P, D, depth = self._packed, self.embed_dim, self.depth
-        if n * depth * 16 * D * 4 > self.MODCACHE_MAX_BYTES or D % 64 != 0:
-            return {}
-        dev = mod_all.device
-        m = mod_all[:, :depth * 6 * D].reshape(n, depth, 6, D)
-        ones = torch.ones(n, D, device=dev)
-        cs = torch.empty(n, depth, 2, D, device=dev)
-        uc = torch.empty(n, depth, 14 * D, device=dev)
-        hi, lo, t32, acc32 = (torch.empty(n, D, device=dev, dtype=torch.bfloat16), torch.empty(n, D, device=dev, dtype=torch.bfloat16),
-                              torch.empty(n, D, device=dev), None)
-
-        def matvec(rows_f32, w, bias, out):                      # out[n, N] = rows W^T (+ b) at fp32 operand accuracy: bf16 hi + lo passes
-            ops.cast_bf16(rows_f32, hi)
-            ops.lincomb(rows_f32, [hi.float()], [-1.0], t32)
-            ops.cast_bf16(t32, lo)
-            tmp = torch.empty_like(out)
-            ops.gemm(hi, w, bias, ops.EPI_F32, out)
-            ops.gemm(lo, w, None, ops.EPI_F32, tmp)
-            ops.axpby(tmp, out, 1.0, 1.0)
-
-        for i, q in enumerate(P['blocks']):
-            for j, (sh_i, sc_i, w, b, off, width) in enumerate(((0, 1, q['qkv_w'], q['qkv_b'], 0, 3 * D),
-                                                              (3, 4, q['fc1_w'], q['fc1_b'], 6 * D, 4 * D))):
-                one_plus = torch.empty(n, D, device=dev)
-                ops.lincomb(ones, [m[:, i, sc_i].contiguous()], [1.0], one_plus)
-                cs[:, i, j] = one_plus
-                u = torch.empty(n, width, device=dev)
-                c = torch.empty(n, width, device=dev)
-                matvec(one_plus, w, None, u)
-                matvec(m[:, i, sh_i].contiguous(), w, b, c)
-                uc[:, i, off:off + width] = u
-                uc[:, i, off + width:off + 2 * width] = c
-        return {'cs': cs, 'uc': uc}
+        return {'mod': mod_all, 'rows': rows}
 
     def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None,
                 mod_cache=None, **kwargs):
@@ -331,53 +281,29 @@ class DiT_TriLatent(DiT):
         oc = ws.get('oc', (M, H * 64), torch.bfloat16)
         f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
 
-        # r4, opt-in: norm + modulate inside the neighbouring GEMMs (tables of prepare_timesteps); needs full GEMM tiles and one shared
-        # timestep.  Off by default: the same-box A/B has it 1.3 - 2 % SLOWER (DESIGN.md, r4 norm fusion)
-        fold = cc.get('fold', 0)
-        fuse = (mod_cache is not None and mod_cache[0].get('uc') is not None and mod_cache[0]['rows'] == 1 and N >= 32
-                and NORM_FUSE()
-                and ops.norm_fusable(M, D, True) and ops.norm_fusable(M - fold * N, D, True)              # proj / fc2, cross-attention out
-                and ops.norm_fusable(M, 3 * D, False, head_split=True) and ops.norm_fusable(M, 4 * D, False))   # QKV, fc1
-        if fuse:
-            cs_t, uc_t = mod_cache[0]['cs'][mod_cache[1]], mod_cache[0]['uc'][mod_cache[1]]      # [depth, 2, D], [depth, 14 D]
-            st = ws.get('rowstats', (M, D // 64, 2), torch.float32)
         probe = getattr(self, '_fc1_probe', None)
-        fused_cross = (N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
-                       and not os.environ.get('LN3D_NO_FUSED_CROSS'))
+        fused_cross = N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
         fold = cc.get('fold', 0)
         r0 = fold * N                                          # first token row that still runs the cross-attention GEMMs
         for i, q in enumerate(P['blocks']):
             o6 = i * 6 * D
             sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
             sh_m, sc_m, g_m = mod[:, o6 + 3 * D:], mod[:, o6 + 4 * D:], mod[:, o6 + 5 * D:]
-            if fuse and i > 0:        # norm1 of this block: applied inside the QKV projection on the previous block's modulated copy
-                ao = self_attention_hip(ws, 'sa_', xb, Bn, N, D, H, q['qkv_w'], q['qkv_b'],
-                                        norm_kw=dict(row_stats=st, row_eps=1e-6, col_u=uc_t[i, 0:], col_c=uc_t[i, 3 * D:], col_ld=0, col_rows=M))
-            else:
-                ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=ld)
-                ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
-            # samples [0, fold) have a constant cross-attention output (prepare_context): it rides on this epilogue as a per-sample row.
-            # fused norm2: their rows of the bf16 copy already carry (1 + s) of norm2 (they see no further update before the MLP), the
-            # other samples' rows stay plain for the cross-attention query projection
-            nf = dict(copy_scale=cs_t[i, 1], copy_scale_rows=r0, row_stats_out=st) if fuse else {}
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=ld)
+            ao = self_attention_hip(ws, 'sa_', hb, Bn, N, D, H, q['qkv_w'], q['qkv_b'])
+            # samples [0, fold) have a constant cross-attention output (prepare_context): it rides on this epilogue as a per-sample row
             ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt, xb, gate=g_a, gate_rows=N, gate_ld=ld,
-                     res_bias=cc['const'][i] if fold else None, res_bias_ld=D, **nf)
+                     res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
             # cross attention on x (no pre-norm, no gate; reference :318) for the remaining samples
             if fused_cross:     # q projection + attention over the cached text context in ONE kernel (q stays in registers)
                 ops.gemm(xb[r0:], q['cq_w'], None, ops.EPI_CROSS_ATTN, oc[r0:], cc['kp'][i][fold:], cc['vt'][i][fold:], M=M - r0, tokens=N, heads=H,
                          head_dim=64, ctx_keys=cc['Lc'], ctx_pad=cc['lpad'], ctx_scale=64 ** -0.5)
-            else:
+            else:               # shapes the fused epilogue does not take (tokens % 192, heads * 64 % 256, more than 96 context keys)
                 ops.gemm(xb[r0:], q['cq_w'], None, ops.EPI_HEADS, qc, M=M - r0, tokens=N, tok_pad=N, heads=H, head_dim=64)
                 ops.attention(qc, cc['k'][i][fold:], cc['vt'][i][fold:], oc[r0:], Bn - fold, H, N, N, cc['Lc'], cc['lpad'], 64)
-            if fuse:                  # the cross-attention update emits the norm2-modulated copy + statistics of its rows
-                ops.gemm(oc[r0:], q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt[r0:], xb[r0:], gate_rows=N, copy_scale=cs_t[i, 1],
-                         row_stats_out=st[r0:])
-                fc1 = lambda: ops.gemm(xb, q['fc1_w'], None, ops.EPI_GELU_ERF, f1, row_stats=st, row_eps=1e-6, col_u=uc_t[i, 6 * D:],
-                                       col_c=uc_t[i, 10 * D:], col_ld=0, col_rows=M)
-            else:
-                ops.gemm(oc[r0:], q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt[r0:])
-                ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=ld)
-                fc1 = lambda: ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
+            ops.gemm(oc[r0:], q['co_w'], q['co_b'], ops.EPI_GATE_RES, xt[r0:])
+            ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_m, scale=sc_m, mod_rows=N, mod_ld=ld)
+            fc1 = lambda: ops.gemm(hb, q['fc1_w'], q['fc1_b'], ops.EPI_GELU_ERF, f1)
             if probe is not None and i == probe['layer'] and len(probe['events']) < probe['max']:
                 # measurement hook (bench.py): HIP events on the launch stream around this one GEMM, inside the real step
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -387,11 +313,7 @@ class DiT_TriLatent(DiT):
                 probe['events'].append((e0, e1))
             else:
                 fc1()
-            if fuse and i + 1 < depth:   # the MLP's residual update emits the NEXT block's norm1-modulated copy + statistics
-                ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, xb, gate=g_m, gate_rows=N, gate_ld=ld, copy_scale=cs_t[i + 1, 0],
-                         row_stats_out=st)
-            else:
-                ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=ld)
+            ops.gemm(f1, q['fc2_w'], q['fc2_b'], ops.EPI_GATE_RES, xt, gate=g_m, gate_rows=N, gate_ld=ld)
 
         of = depth * 6 * D
         out = torch.empty(Bn, self.out_channels * 3, S, S, dtype=torch.float32, device=dev)

@@ -319,18 +319,6 @@ def _save_ppm(path, frame):
         f.write(b'P6 %d %d 255\n' % (f0.shape[1], f0.shape[0]) + f0.tobytes())
 
 
-def _save_video(path, frames):
-    """Orbit video of one sample, frames [V, 3, R, R] in [-1, 1] -> animated GIF through Pillow (the reference writes an mp4 with
-    imageio, nsr/train_util_diffusion.py:252; no video encoder exists in this environment).  Returns False without Pillow."""
-    try:
-        from PIL import Image
-    except ImportError:
-        return False
-    ims = [Image.fromarray(np.clip((f.transpose(1, 2, 0) + 1) * 127.5, 0, 255).astype(np.uint8)) for f in frames]
-    ims[0].save(path, save_all=True, append_images=ims[1:], duration=66, loop=0)
-    return True
-
-
 def run(args, objaverse=None):
     objaverse = getattr(args, 'entry_objaverse', True) if objaverse is None else objaverse
     from . import parallel
@@ -436,12 +424,6 @@ def run(args, objaverse=None):
     for j, (smp, view) in enumerate(frames['pair_index'].tolist()):
         if view == 0:
             _save_ppm(os.path.join(args.logdir, f'sample{smp}_view0.ppm'), fr[j])
-    # per-sample orbit video for every sample whose views all sit on this rank (always the case with at least as many samples as ranks)
-    pairs = frames['pair_index'].tolist()
-    for smp in sorted({s_ for s_, _ in pairs}):
-        idx = sorted((view, j) for j, (s_, view) in enumerate(pairs) if s_ == smp)
-        if len(idx) == V and V > 1:
-            _save_video(os.path.join(args.logdir, f'sample{smp}_video.gif'), [fr[j] for _, j in idx])
     if rank == 0:
         np.save(os.path.join(args.logdir, 'latents_all.npy'), lat_all.cpu().numpy())
         print(f"[rank0] {kind}: sampled {Bt} latents ({P} condition(s) x {args.num_samples}) and rendered {Bt * V} views on {world} GPU(s); "

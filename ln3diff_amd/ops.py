@@ -24,15 +24,13 @@ def _chk_dev(*ts):
 
 
 def reload_env():
-    """Re-read the library's measurement switches (LN3D_GEMM_TILE, LN3D_ATTN_V, ...: they are parsed once per process)."""
+    """Re-read the library's one measurement switch (LN3D_GEMM_TILE, the tile override the tests sweep: parsed once per process)."""
     L.lib().ln3d_reload_env()
 
 
 def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, gate=None, gate_rows=1,
          gate_ld=0, tokens=0, tok_pad=0, heads=0, head_dim=0, transpose_mask=0, head_dim_pad=0, ctx_keys=0, ctx_pad=0,
-         ctx_scale=0.0, head_norm0=None, head_norm1=None, head_norm_eps=1e-5, res_bias=None, res_bias_ld=0,
-         copy_scale=None, copy_scale_ld=0, copy_scale_rows=None, row_stats_out=None,
-         row_stats=None, row_eps=1e-6, row_norm_kind=0, col_u=None, col_c=None, col_ld=0, col_rows=1):
+         ctx_scale=0.0, head_norm0=None, head_norm1=None, head_norm_eps=1e-5, res_bias=None, res_bias_ld=0):
     """out = epi(x[M,K] @ w[N,K]^T + bias).  x, w bf16 (row stride = shape[-1])."""
     _chk_dev(x, w, out0)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -53,27 +51,13 @@ def gemm(x, w, bias, epilogue, out0, out1=None, out2=None, *, M=None, ldo=None, 
     a.ctx_keys, a.ctx_pad, a.ctx_scale = ctx_keys, ctx_pad, float(ctx_scale)
     a.head_norm0, a.head_norm1, a.head_norm_eps = _p(head_norm0), _p(head_norm1), float(head_norm_eps)
     a.res_bias, a.res_bias_ld = _p(res_bias), int(res_bias_ld)
-    # norm + modulate fused into the GEMMs around it (ABI 8): producer side (GATE_RES) / consumer side
-    a.copy_scale, a.copy_scale_ld = _p(copy_scale), int(copy_scale_ld)
-    a.copy_scale_rows = int(a.M if copy_scale_rows is None else copy_scale_rows)
-    a.row_stats_out = _p(row_stats_out)
-    a.row_stats, a.row_stats_parts, a.row_eps, a.row_norm_kind = _p(row_stats), (K // 64 if row_stats is not None else 0), float(row_eps), int(row_norm_kind)
-    a.col_u, a.col_c, a.col_ld, a.col_rows = _p(col_u), _p(col_c), int(col_ld), int(col_rows)
     L.check(L.lib().ln3d_gemm_bf16(C.byref(a), _stream()), "gemm")
 
 
 def heads_norm_fusable(M, N, tokens, head_dim, head_dim_pad=0):
     """True when ln3d_gemm_bf16's HEADS epilogue applies qk_norm itself for this problem - the library's own answer (it depends on
     the tile configuration it picks), not a copy of its heuristic."""
-    import os
-    if os.environ.get('LN3D_NO_FUSED_QKNORM'):
-        return False
     return bool(L.lib().ln3d_gemm_heads_norm_fusable(int(M), int(N), int(tokens), int(head_dim), int(head_dim_pad)))
-
-
-def norm_fusable(M, N, producer, head_split=False):
-    """True when ln3d_gemm_bf16 serves the fused-norm arguments for an [M, N] problem on that side (the library's own answer)."""
-    return bool(L.lib().ln3d_gemm_norm_fusable(int(M), int(N), 1 if producer else 0, 1 if head_split else 0))
 
 
 def attention(q, k, vt, out, B, H, Nq, Nq_pad, Nk, Nk_pad, Dh, scale=None, causal=False, dh_true=0):

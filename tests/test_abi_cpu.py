@@ -48,7 +48,7 @@ NULL_CALLS = {
     'ln3d_im2col3x3': (N, N, 1, 8, 8, 64, 1, 576, N),
     'ln3d_stream_create_cu_mask': (N, 1, N),
 }
-NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_gemm_norm_fusable', 'ln3d_device_cus', 'ln3d_stream_cu_count'}      # pure host queries
+NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_device_cus', 'ln3d_stream_cu_count'}      # pure host queries
 
 
 def test_every_entry_point_rejects_missing_buffers(hip_lib):

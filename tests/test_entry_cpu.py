@@ -139,14 +139,14 @@ def test_renderer_variants_outside_the_hot_path_are_refused():
             Triplane(img_resolution=16, **kw)
 
 
-def test_encoded_images_are_read_through_pillow_and_videos_written(tmp_path):
-    """--image_path accepts what Pillow decodes (RGBA composited on white, as the released demo inputs are), and the per-sample orbit
-    video is an animated GIF (the reference's mp4 writer needs imageio, absent here)."""
+def test_encoded_images_are_read_through_pillow(tmp_path):
+    """--image_path accepts what Pillow decodes (RGBA composited on white, as the released demo inputs are).  Video encoding is outside
+    the metric and the hot path: frames leave as .npy arrays + a .ppm per sample."""
     PIL = pytest.importorskip("PIL")
     from PIL import Image
     import numpy as np
     import torch
-    from ln3diff_amd.entry import _read_image, _save_video
+    from ln3diff_amd.entry import _read_image
     rgba = np.zeros((8, 6, 4), np.uint8)
     rgba[..., 0] = 255                     # red ...
     rgba[:4, :, 3] = 255                   # ... opaque in the top half, transparent below
@@ -156,8 +156,3 @@ def test_encoded_images_are_read_through_pillow_and_videos_written(tmp_path):
     assert a.shape == (1, 3, 8, 6) and float(a.min()) >= -1.0 and float(a.max()) <= 1.0
     assert torch.allclose(a[0, :, 0, 0], torch.tensor([1.0, -1.0, -1.0]))            # opaque red
     assert torch.allclose(a[0, :, 7, 0], torch.tensor([1.0, 1.0, 1.0]))              # transparent -> white background
-    frames = [np.full((3, 16, 16), -1.0 + 0.5 * i, np.float32) for i in range(4)]
-    v = str(tmp_path / "v.gif")
-    assert _save_video(v, frames)
-    im = Image.open(v)
-    assert getattr(im, "n_frames", 1) == 4 and im.size == (16, 16)

@@ -232,56 +232,33 @@ def test_gemm_heads_split_with_fused_qk_norm(ops, B, T, H, K):
                  head_norm0=nq)
 
 
-@pytest.mark.parametrize("kind,mean_shift", [(0, 0.0), (0, 1.5), (1, 0.0)])
-def test_gemm_fused_norm_producer_consumer(hip_lib, auto_tile, kind, mean_shift):
-    """r4 (ABI 8): LayerNorm / RMSNorm + modulate applied inside the GEMMs around it.  Producer: the gate/residual epilogue writes
-    bf16(x * (1 + s)) (plain copies from copy_scale_rows on) and (sum, sum^2) partials per 64 features; consumer: out = rs * (acc -
-    mu * u) + c with u = W (1 + s), c = W sh + b.  Against fp32 torch, and against the unfused kernel sequence (residual update ->
-    ln3d_norm_modulate -> GEMM), also with a row mean of 1.5 sigma (the error amplification of the un-centred bf16 copy is
-    sqrt(1 + (mu / sigma)^2): bounded here, and measured on the real network in tests/test_geometry_gpu.py)."""
+def test_gemm_gelu_erf_epilogue_tail(hip_lib, auto_tile):
+    """the GELU-erf epilogue is a polynomial erf.  Against torch's exact erf-GELU on inputs that cover the negative tail
+    ([-6, 6], every fc1 / ViT / CLIP / DINO MLP goes through it): absolute error <= 1.5e-4 + the bf16 rounding of the output, and the
+    result has the sign of its argument (the r4 form returned +2e-6 below x = -3.9987)."""
     from ln3diff_amd import ops
     dev = 'cuda'
-    M, D, N2, T = 16 * 192, 1024, 4096, 192
-    g = torch.Generator().manual_seed(kind * 7 + int(mean_shift * 10))
-    x0 = (torch.randn(M, D, generator=g) + mean_shift).to(dev)
-    a = _bf(torch.randn(M, D, generator=g).to(dev))
-    wp = _bf((torch.randn(D, D, generator=g) * 0.03).to(dev)); bp = (torch.randn(D, generator=g) * 0.1).to(dev)
-    gate = torch.randn(M // T, D, generator=g).to(dev)
-    s = (torch.randn(D, generator=g) * 0.3).to(dev); sh = (torch.randn(D, generator=g) * 0.3).to(dev)
-    w1 = _bf((torch.randn(N2, D, generator=g) * 0.03).to(dev)); b1 = (torch.randn(N2, generator=g) * 0.1).to(dev)
-    # fp32 reference
-    xr = x0 + gate.repeat_interleave(T, 0) * (a.float() @ wp.float().t() + bp)
-    if kind == 0:
-        yr = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6) * (1 + s) + sh
-    else:
-        yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * (1 + s) + sh
-    ref = torch.nn.functional.gelu(yr @ w1.float().t() + b1)
-    # unfused kernels
-    x1 = x0.clone(); h = torch.empty(M, D, device=dev, dtype=torch.bfloat16); o1 = torch.empty(M, N2, device=dev, dtype=torch.bfloat16)
-    ops.gemm(a, wp, bp, ops.EPI_GATE_RES, x1, gate=gate, gate_rows=T, gate_ld=D)
-    ops.norm_modulate(x1, h, M, D, kind=kind, eps=1e-6, shift=sh, scale=s, mod_rows=M, mod_ld=0)
-    ops.gemm(h, w1, b1, ops.EPI_GELU_ERF, o1)
-    # fused: rows from `plain_from` on stay plain copies (the DiT's conditional samples before the cross-attention update)
-    plain_from = M - 2 * T
-    x2 = x0.clone(); xm = torch.empty(M, D, device=dev, dtype=torch.bfloat16); st = torch.zeros(M, D // 64, 2, device=dev)
-    one_plus = (1 + s).contiguous()
-    ops.gemm(a, wp, bp, ops.EPI_GATE_RES, x2, xm, gate=gate, gate_rows=T, gate_ld=D, copy_scale=one_plus, copy_scale_rows=plain_from, row_stats_out=st)
-    assert torch.equal(x2, x1)
-    assert torch.equal(xm[plain_from:], _bf(x2[plain_from:])) and torch.equal(xm[:plain_from], _bf(x2[:plain_from] * one_plus))
-    xs = x2.reshape(M, D // 64, 64)
-    assert rel_l2(st[..., 0], xs.sum(-1)) < 1e-5 and rel_l2(st[..., 1], xs.pow(2).sum(-1)) < 1e-5
-    xm[plain_from:] = _bf(x2[plain_from:] * one_plus)                                  # what the second producer (cross-attention out) would write
-    u = (w1.float() @ one_plus).contiguous(); c = (w1.float() @ sh + b1).contiguous()
-    o2 = torch.empty(M, N2, device=dev, dtype=torch.bfloat16)
-    ops.gemm(xm, w1, None, ops.EPI_GELU_ERF, o2, row_stats=st, row_eps=1e-6, row_norm_kind=kind, col_u=u, col_c=c, col_ld=0, col_rows=M)
-    e_unf, e_fus, e_pair = rel_l2(o1.float(), ref), rel_l2(o2.float(), ref), rel_l2(o2.float(), o1.float())
-    print(f'fused norm kind {kind} mean/sigma {mean_shift}: unfused vs fp32 {e_unf:.2e}, fused vs fp32 {e_fus:.2e}, fused vs unfused {e_pair:.2e}')
-    assert e_unf < 6e-3 and e_fus < 6e-3 * (1 + mean_shift ** 2) ** 0.5 * 1.5
-    # arguments the library cannot serve are refused, not ignored
-    with pytest.raises(RuntimeError):
-        ops.gemm(xm, w1, b1, ops.EPI_GELU_ERF, o2, row_stats=st, col_u=u, col_c=c)      # bias next to col_c
-    with pytest.raises(RuntimeError):
-        ops.gemm(a[:100], wp, bp, ops.EPI_GATE_RES, x2[:100], xm[:100], gate_rows=100, copy_scale=one_plus, row_stats_out=st)   # small-problem kernel
+    M, K, N = 2048, 64, 256
+    x = torch.zeros(M, K, device=dev)
+    vals = torch.linspace(-6, 6, M * N // 1, device=dev)[:M * 4].reshape(M, 4)      # 4 probe values per row, routed by one-hot weights
+    grid = torch.linspace(-6.0, 6.0, M * 4, device=dev).reshape(M, 4)
+    x[:, :4] = grid
+    w = torch.zeros(N, K, device=dev)
+    w[torch.arange(N), torch.arange(N) % 4] = 1.0                                  # feature n reads probe n % 4
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, wb, None, ops.EPI_GELU_ERF, out)
+    arg = xb.float()[:, :4].repeat(1, N // 4).reshape(M, N // 4, 4).reshape(M, N)   # feature n's argument = probe n % 4
+    arg = xb.float()[:, torch.arange(N, device=dev) % 4]
+    ref = torch.nn.functional.gelu(arg.double()).float()
+    got = out.float()
+    err = (got - ref).abs()
+    bound = 1.5e-4 + ref.abs() * 2.0 ** -8
+    assert bool((err <= bound).all()), float((err - bound).max())
+    neg, pos = arg < 0, arg > 0
+    assert bool((got[neg] <= 0).all()) and bool((got[pos] >= 0).all())
+    tail = arg <= -4.0
+    assert tail.any() and float(got[tail].abs().max()) <= 3e-5
 
 
 def _attn_ref(q, k, v, scale):

@@ -7,7 +7,7 @@ import re
 import pytest
 import torch
 
-from conftest import ROOT, load_synth, rel_l2
+from conftest import ROOT, golden, load_synth, rel_l2
 
 pytestmark = pytest.mark.gpu
 

@@ -44,7 +44,7 @@ static uint64_t fnv(const void* p, size_t n) {
 static float bf2f_h(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static float gelu_h(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-struct Case { const char* name; int M, N, K, epi; int tokens; const char* tile; int fused = 0; };   // fused: 1 = norm consumer side (row_stats / col_u / col_c)
+struct Case { const char* name; int M, N, K, epi; int tokens; const char* tile; };
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 3;
@@ -65,9 +65,6 @@ int main(int argc, char** argv) {
       {"fc1 plain x7 (r3 tile)", 12288, 4096, 1024, LN3D_EPI_BF16, 768, "x7"},
       {"qkv HEADS x12 (r3 tile)", 12288, 3072, 1024, LN3D_EPI_HEADS, 768, "x12"},
       {"qkv plain x12 (r3 tile)", 12288, 3072, 1024, LN3D_EPI_BF16, 768, "x12"},
-      {"fc1 GELU fused-norm x7", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x7", 1},
-      {"fc1 GELU fused-norm x9", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x9", 1},
-      {"qkv HEADS fused-norm x9", 12288, 3072, 1024, LN3D_EPI_HEADS, 768, "x9", 1},
       {"fc1 GELU x9 (256x192)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x9"},
       {"fc1 GELU x12 (384x192)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x12"},
       {"qkv HEADS x9 (256x192)", 12288, 3072, 1024, LN3D_EPI_HEADS, 768, "x9"},
@@ -116,13 +113,6 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(o0, 0, o0b, st));
     if (c.epi == LN3D_EPI_CROSS_ATTN) { fill_bf16<<<1024, 256, 0, st>>>((bf16_t*)o1, o1b / 2, 16, 1.0f); fill_bf16<<<1024, 256, 0, st>>>((bf16_t*)o2, o2b / 2, 17, 1.0f); }
     a.out0 = o0; a.out1 = o1; a.out2 = o2;
-    float *stats = nullptr, *cu = nullptr, *ccv = nullptr;
-    if (c.fused == 1) {
-      CK(hipMalloc(&stats, (size_t)M * (K / 64) * 2 * 4)); CK(hipMalloc(&cu, N * 4)); CK(hipMalloc(&ccv, N * 4));
-      fill_f32<<<1024, 256, 0, st>>>(stats, (int64_t)M * (K / 64) * 2, 21, 1.0f);
-      fill_f32<<<64, 256, 0, st>>>(cu, N, 22, 0.1f); fill_f32<<<64, 256, 0, st>>>(ccv, N, 23, 0.1f);
-      a.bias = nullptr; a.row_stats = stats; a.row_stats_parts = K / 64; a.row_eps = 1e-6f; a.row_norm_kind = 1; a.col_u = cu; a.col_c = ccv; a.col_ld = 0; a.col_rows = M;
-    }
     // ---- one checked run
     if (o0_init) CK(hipMemcpyAsync(o0, o0_init, o0b, hipMemcpyDeviceToDevice, st));
     int rc = ln3d_gemm_bf16(&a, st);
@@ -135,7 +125,7 @@ int main(int argc, char** argv) {
       hs ^= fnv(h1.data(), o1b) * 3 ^ fnv(h2.data(), o2b) * 5;
     }
     double maxerr = -1.0;
-    if (!c.fused && (c.epi == LN3D_EPI_BF16 || c.epi == LN3D_EPI_GELU_ERF || c.epi == LN3D_EPI_GATE_RES)) {
+    if ((c.epi == LN3D_EPI_BF16 || c.epi == LN3D_EPI_GELU_ERF || c.epi == LN3D_EPI_GATE_RES)) {
       const int NS = 4096; int *mi, *ni; float* ref;
       CK(hipMalloc(&mi, NS * 4)); CK(hipMalloc(&ni, NS * 4)); CK(hipMalloc(&ref, NS * 4));
       ref_samples<<<NS / 64, 64, 0, st>>>(X, W, M, N, K, NS, mi, ni, ref);
