@@ -280,6 +280,13 @@ class EulerEDMSampler:
                 st = self._prepare(den, network, x[a:b], sl(cond, a, b), sl(uc, a, b), n)
                 st['mod'] = mod_shared if shared_ok else self._mod_all(network, st['quant'], n, b - a)
                 sts.append(st)
+        # lanes that start together run the same kernel at the same time and keep doing so (identical work): a start offset
+        # (LN3D_LANE_SKEW_US per lane index, default a third of a DiT-L/2 layer) puts one lane's HBM-bound phases under another's MFMA loops
+        skew_us = float(os.environ.get('LN3D_LANE_SKEW_US', '150'))
+        if skew_us > 0:
+            for k in range(1, lanes):
+                with torch.cuda.stream(streams[k]):
+                    torch.cuda._sleep(int(skew_us * k * 2000))           # spin cycles at ~2 GHz
         for i in range(n):
             for k in range(lanes):
                 with torch.cuda.stream(streams[k]):

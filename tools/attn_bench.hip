@@ -45,9 +45,7 @@ int main() {
   const int Dh = 64;
   const Case cases[] = {{16, 16, 768, 768, 0}, {16, 16, 768, 768, 1}, {16, 16, 1024, 1024, 0}, {32, 16, 512, 512, 1}, {32, 16, 512, 512, 0},
                         {2, 16, 768, 768, 1}, {1, 4, 700, 1000, 1}, {2, 3, 300, 832, 1}, {1, 2, 257, 257, 1}};
-  const struct { const char* name; int ver, kres; } variants[] = {
-      {"r1 ring kernel", 2, 1}, {"r2 stream kernel", 3, 1}, {"r3 kres", 0, 0}, {"r3 kres +prio", 0, 1}, {"r3 kres +st", 0, 2}, {"r3 kres +prio+st", 0, 3}
-      };
+  const struct { const char* name; } variants[] = {{"shipped kernel"}};     // r5: one kernel per shape class, no switches left
   const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
   int ci = 0;
   for (const Case& c : cases) {
@@ -86,9 +84,6 @@ int main() {
     int vi = 0;
     for (const auto& var : variants) {
       if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
-      attn_cfg();                                          // environment parsed (once), then overridden per variant
-      g_attn_cfg.ver = var.ver; g_attn_cfg.kres = var.kres;
-      if (var.ver == 0 && var.kres != 1 && !(c.Nk >= 512 && c.Nk <= 768 && (c.Nq & 255) == 0 && c.B * c.H >= 256)) continue;   // same kernel as the default
       hipMemset(o, 0xff, no * 2);
       const int rc = ln3d_attention_bf16(&a, nullptr);
       hipError_t e = hipDeviceSynchronize();
