@@ -4,7 +4,7 @@ Surface of the reference's transport package for the sampling path: create_trans
 Sampler(transport).sample_ode(sampling_method, num_steps, atol, rtol, reverse)(x, model_fn, **kw) -> [T, ...]
 (transport/__init__.py:3-71, transport/transport.py:374-420, transport/integrators.py:78-120).
 Linear path + velocity prediction: dx/dt = model(x, t), t from 0 (noise) to 1 (data).  Fixed-grid
-'euler' and 'heun' plus adaptive Dormand-Prince 5(4) with dense output ('dopri5', the reference's default; restated from the
+'euler', 'heun', 'midpoint' and 'rk4' (torchdiffeq's fixed-grid definitions: its RK4 is the 3/8 rule) plus adaptive Dormand-Prince 5(4) with dense output ('dopri5', the reference's default; restated from the
 published algorithm of the absent third-party torchdiffeq 0.2.3: parity unpinned against the package - SURVEY.md §8c; pinned to
 oracle/samplers.py's restatement step for step, and validated by convergence to the fixed-step solution).
 """
@@ -34,8 +34,8 @@ class Sampler:
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False, cfg=False):
         if sampling_method == "dopri5":
             return _dopri5_sampler(num_steps, atol, rtol)
-        if sampling_method not in ("euler", "heun"):
-            raise NotImplementedError(f"ODE method '{sampling_method}'")
+        if sampling_method not in ("euler", "heun", "midpoint", "rk4"):
+            raise NotImplementedError(f"ODE method '{sampling_method}' (fixed grid: euler, heun, midpoint, rk4; adaptive: dopri5)")
         assert not reverse
         ts = torch.linspace(0.0, 1.0, num_steps)
 
@@ -52,6 +52,26 @@ class Sampler:
                 k1 = model_fn(x, t_dev, **model_kwargs)
                 if sampling_method == "euler":
                     ops.axpby(k1, x, dt, 1.0)
+                elif sampling_method == "midpoint":      # torchdiffeq Midpoint._step_func: dt * f(t0 + dt/2, y0 + dt/2 f0)
+                    xm = torch.empty_like(x)
+                    ops.lincomb(x, [k1], [0.5 * dt], xm)
+                    t_dev.fill_(t0 + 0.5 * dt)
+                    k2 = model_fn(xm, t_dev, **model_kwargs)
+                    ops.axpby(k2, x, dt, 1.0)
+                elif sampling_method == "rk4":           # torchdiffeq RK4 = rk4_alt_step_func, the 3/8 rule (rk_common.py)
+                    xs = torch.empty_like(x)
+                    ops.lincomb(x, [k1], [dt / 3], xs)
+                    t_dev.fill_(t0 + dt / 3)
+                    k2 = model_fn(xs, t_dev, **model_kwargs)
+                    xs = torch.empty_like(x)
+                    ops.lincomb(x, [k2, k1], [dt, -dt / 3], xs)
+                    t_dev.fill_(t0 + dt * 2 / 3)
+                    k3 = model_fn(xs, t_dev, **model_kwargs)
+                    xs = torch.empty_like(x)
+                    ops.lincomb(x, [k1, k2, k3], [dt, -dt, dt], xs)
+                    t_dev.fill_(t1)
+                    k4 = model_fn(xs, t_dev, **model_kwargs)
+                    ops.lincomb(x, [k1, k2, k3, k4], [dt / 8, 3 * dt / 8, 3 * dt / 8, dt / 8], x)
                 else:
                     xe = x.clone()
                     ops.axpby(k1, xe, dt, 1.0)

@@ -228,6 +228,15 @@ def flow_ode_sample(model_fn, x, num_steps=50, method="euler", **model_kwargs):
             k1 = f(t0, x)
             k2 = f(t1, x + dt * k1)
             x = x + dt * 0.5 * (k1 + k2)
+        elif method == "midpoint":        # torchdiffeq 0.2.3 fixed_grid.Midpoint (third-party, absent: parity unpinned against the package)
+            k1 = f(t0, x)
+            x = x + dt * f(t0 + 0.5 * dt, x + 0.5 * dt * k1)
+        elif method == "rk4":             # torchdiffeq 0.2.3 fixed_grid.RK4 -> rk_common.rk4_alt_step_func: the 3/8 rule
+            k1 = f(t0, x)
+            k2 = f(t0 + dt / 3, x + dt * k1 / 3)
+            k3 = f(t0 + dt * 2 / 3, x + dt * (k2 - k1 / 3))
+            k4 = f(t1, x + dt * (k1 - k2 + k3))
+            x = x + dt * (k1 + 3 * (k2 + k3) + k4) / 8
         else:
             raise ValueError(method)
     return x

@@ -338,7 +338,32 @@ def sec_ddim():
         save(f'ddim_tiny_{spec}', final=y_ref, eta=np.array(eta), scale=np.array(s), noise_seed=np.array(seed))
 
 
-SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim}
+def sec_flow_fixed():
+    """The remaining fixed-grid methods transport.integrators.ode hands to odeint (integrators.py:78-119): 'midpoint' and 'rk4' through the
+    reference's Sampler.sample_ode on the tiny I23D network.  odeint itself is ref_shims' stand-in (torchdiffeq is absent from the image):
+    what is pinned is the reference's grid / drift / CFG plumbing around it; the step formulas restate torchdiffeq 0.2.3 (parity
+    unpinned against the package)."""
+    print('== flow-matching fixed-grid midpoint / rk4')
+    m = build_i23d(128, 2, 2)
+    sd, shapes = load_synth(m, 0)
+    B = 2
+    from transport import create_transport, Sampler
+    tr = create_transport(path_type='Linear', prediction='velocity', snr_type='lognorm')
+    z = synth_input('z', (B, 12, 32, 32), 42)
+    zs = torch.cat([z, z], 0)
+    cond = {'crossattn': synth_input('ca', (B, 256, 2048), 42), 'vector': synth_input('v', (B, 768), 42)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    context = {k: torch.cat([cond[k], uc[k]], 0) for k in cond}
+    for method, steps in (('midpoint', 10), ('rk4', 6)):
+        fn = Sampler(tr).sample_ode(sampling_method=method, num_steps=steps)
+        y_ref = fn(zs.clone(), m.forward_with_cfg, context=context, cfg_scale=4.0)[-1].chunk(2)[0]
+        y_or = osamp.flow_ode_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], kw['cfg_scale'], 2),
+                                     zs.clone(), steps, method, context=context, cfg_scale=4.0).chunk(2)[0]
+        check(f'flow {method} num_steps={steps} final latent', y_or, y_ref, 2e-4)
+        save(f'flow_tiny_{method}{steps}', final=y_ref)
+
+
+SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim, 'flow_fixed': sec_flow_fixed}
 
 if __name__ == '__main__':
     from make_golden_render import sec_render, sec_decoder, sec_render_presets   # noqa: E402

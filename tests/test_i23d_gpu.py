@@ -46,7 +46,7 @@ def test_i23d_pixart_l2_forward_with_cfg(hip_lib):
     assert e < 2e-2, e
 
 
-@pytest.mark.parametrize("method,steps", [('euler', 50), ('heun', 10)])
+@pytest.mark.parametrize("method,steps", [('euler', 50), ('heun', 10), ('midpoint', 10), ('rk4', 6)])
 def test_flow_matching_ode_vs_reference_golden(hip_lib, method, steps):
     from ln3diff_amd.synth import synth_input
     from ln3diff_amd.transport import Sampler, create_transport

@@ -95,14 +95,15 @@ def test_oracle_edm_euler_matches_reference_golden():
     assert abs(float(s250[0]) - 14.6146) < 1e-3 and abs(float(s250[249]) - 0.0586) < 1e-3 and float(s250[250]) == 0
 
 
-def test_oracle_flow_heun_matches_reference_golden():
-    g = golden('flow_tiny_heun10')
+@pytest.mark.parametrize("method,steps", [('heun', 10), ('midpoint', 10), ('rk4', 6)])
+def test_oracle_flow_fixed_grid_matches_reference_golden(method, steps):
+    g = golden(f'flow_tiny_{method}{steps}')
     sd = _sd_from_manifest(golden('i23d_tiny'))
     z = synth_input('z', (2, 12, 32, 32), 42)
     cond = {'crossattn': synth_input('ca', (2, 256, 2048), 42), 'vector': synth_input('v', (2, 768), 42)}
     ctx = {k: torch.cat([v, torch.zeros_like(v)], 0) for k, v in cond.items()}
     y = osamp.flow_ode_sample(lambda x, t, **kw: odit.i23d_forward_with_cfg(sd, x, t, kw['context'], 4.0, 2),
-                              torch.cat([z, z]), 10, 'heun', context=ctx).chunk(2)[0]
+                              torch.cat([z, z]), steps, method, context=ctx).chunk(2)[0]
     assert rel_l2(y, g['final']) < 1e-4
 
 
@@ -152,6 +153,33 @@ def test_oracle_render_matches_reference_golden(tag, res, V):
     if tag.startswith('sparse'):     # the batch-global depth clamp quirk: every pixel == global min depth
         assert float(r['image_depth'].max() - r['image_depth'].min()) == 0.0
     assert np.allclose(orbit_cameras(8)[[1, 6][:V]].numpy(), g['cams'])
+
+
+@pytest.mark.parametrize('tag,optname', [('shapenet64', 'SHAPENET_OPTS'), ('objv96', 'OBJAVERSE_96_OPTS'), ('afhq48', 'AFHQ_48_OPTS')])
+def test_oracle_render_presets_match_reference_golden(tag, optname):
+    """The other sampling presets (numeric ray limits, 48 / 96 samples, no bbox filter, black background) and the seam outputs of
+    ImportanceRenderer.forward (visibility, return_meta's weights / all_coords / feature_volume) against the reference's outputs."""
+    from ln3diff_amd.nsr.triplane import draw_render_noise
+    g = golden('render_preset_' + tag)
+    opts = getattr(orender, optname)
+    cams = torch.from_numpy(g['cams'])
+    res, V = int(g['res']), cams.shape[0]
+    M, S, NI = res * res, opts['depth_resolution'], opts['depth_resolution_importance']
+    planes = synth_input('planes', (V, 96, 128, 128), 3, float(g['plane_scale']))
+    gen = torch.Generator().manual_seed(int(g['jitter_seed']))
+    if opts['ray_start'] == 'auto':
+        j, u = draw_render_noise(V, M, S, generator=gen, n_importance=NI)
+        j = j.unsqueeze(-1)
+    else:
+        j, u = torch.rand(V, M, S, 1, generator=gen), None
+        u = torch.rand(V * M, NI, generator=gen)
+    r = orender.triplane_render(planes, _dec_sd(float(g['sigma_bias'])), cams, res, j, u, opts)
+    for k in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
+        assert rel_l2(r[k], g[k]) < 1e-4, k
+    d = r['detail']
+    assert rel_l2(d['visibility'], g['visibility']) < 1e-4
+    for k in ('weights', 'all_coords', 'feature_volume'):
+        assert rel_l2(d[k], g[k].astype(np.float32)) < 2e-3, k           # stored as fp16
 
 
 def test_oracle_grid_matches_reference_golden():
