@@ -320,8 +320,11 @@ struct RunEpi {
   }
 };
 
-template <int EPI, int NI, int NJ, bool DBUF = true>
-__device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane) {
+// `pre` / `pre_re`: GATE_RES interior tiles - the residual batch and the bias / gate rows of block 0, requested by the caller in
+// front of the LAST K stage so that their L2 / fabric round trip runs under that stage's MFMAs (r5); null = fetched here.
+template <int EPI, int NI, int NJ, bool DBUF = true, bool PRE = false>
+__device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], char* stg, int fw0, int tw0, int lane,
+                                                const float4 (&pre)[8], const RunEpi<EPI>& pre_re, bool have_pre) {
   constexpr bool kPreAct = EPI == LN3D_EPI_GELU_ERF || EPI == LN3D_EPI_GELU_TANH || EPI == LN3D_EPI_SILU || EPI == LN3D_EPI_QUICK_GELU;
   constexpr bool kBf16Out = kPreAct || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_CROSS_ATTN;
   const bool wide = kBf16Out && (p.N & 7) == 0 && (p.ldo & 7) == 0;
@@ -360,8 +363,14 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
       auto blk_fb = [&](int blk) __attribute__((always_inline)) { return fw0 + (blk / NJ) * 64 + 4 * rc; };
       auto blk_tb = [&](int blk) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tw0 + (blk % NJ) * 32); };
       RunEpi<EPI> re_cur, re_nxt;
-      re_cur.init(p, blk_fb(0), blk_tb(0), 0, 0, 0);
-      fetch(0, xres[0]);
+      if (PRE && have_pre) {             // have_pre is wave-uniform and implied by `full` (same predicate at the call site)
+        re_cur = pre_re;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) xres[0][it] = pre[it];
+      } else {
+        re_cur.init(p, blk_fb(0), blk_tb(0), 0, 0, 0);
+        fetch(0, xres[0]);
+      }
 #pragma unroll
       for (int blk = 0; blk < NBLK; ++blk) {
         const int ih = blk / NJ, j = blk % NJ;
@@ -558,6 +567,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
 #ifndef LN3D_RING_D1
 #define LN3D_RING_D1 0       // DMA pieces of a stage issued right behind the barrier (0 = half of them); the rest in the next two substeps
 #endif
+#ifndef LN3D_RING_PRE
+#define LN3D_RING_PRE 1     // bench builds only: 0 = no residual prefetch under the last K stage (the r4 epilogue)
+#endif
 #ifndef LN3D_RING_ABL
 #define LN3D_RING_ABL 0     // bench builds only: 1 = skip the epilogue, 2 = two K stages only, 4 = no DMA in the steady state, 8 = per-stage s_memtime stamps into out2
 #endif
@@ -752,6 +764,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   } else if (ns == 2) {
     Y_STAGE(0, false, false, true);
     s = 1;
+  }
+  // GATE_RES, interior tile: block 0's residual quads (8 rows x 16 B per lane) and its bias / gate rows are requested here, one K stage
+  // before the accumulators are final - the epilogue then starts on data that has arrived instead of on an L2 / fabric round trip
+  constexpr bool kPre = LN3D_RING_PRE && EPI == LN3D_EPI_GATE_RES && NW <= 8 && NI % 2 == 0 && NI * NJ <= 6 && !(ABL & 1);
+  float4 xpre[8];
+  RunEpi<EPI> re_pre;
+  bool have_pre = false;
+  if constexpr (kPre) {
+    const int fw0 = f0 + wf * 32 * NI, tw0 = t0 + wt * 32 * NJ;
+    const bool full = (tw0 + 32 * NJ <= p.M) && (fw0 + 32 * NI <= p.N) && !((p.gate || p.rb) && p.gate_rows < 32);
+    if (__builtin_amdgcn_readfirstlane(full ? 1 : 0)) {
+      have_pre = true;
+      const int rrow = lane >> 4, rc = lane & 15;
+      re_pre.init(p, fw0 + 4 * rc, __builtin_amdgcn_readfirstlane(tw0), 0, 0, 0);
+      const float* base = (const float*)p.out0 + (int64_t)(tw0 + rrow) * p.ldo + fw0 + 4 * rc;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) xpre[it] = *reinterpret_cast<const float4*>(base + (int64_t)(4 * it) * p.ldo);
+    }
   }
   Y_STAGE(s, false, false, false);
 
@@ -979,7 +1009,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     return;
   }
   __builtin_amdgcn_s_barrier();
-  staged_epilogue<EPI, NI, NJ, (NW <= 8)>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane);
+  staged_epilogue<EPI, NI, NJ, (NW <= 8), kPre>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane, xpre, re_pre, have_pre);
 }
 
 template <int EPI, int NW, int WGT, int NI, int NJ>

@@ -129,6 +129,14 @@ __device__ __forceinline__ void ray_box(const float o[3], const float d[3], floa
   tmax_o = valid ? tmax : -2.0f;
 }
 
+// r5: the ray's origin / direction leave make_ray as six separate scalar registers.  With hipcc's SLP vectoriser on, ONE tree that keeps
+// (o0, o1) / (d0, d1) as 64-bit register tuples across the per-ray loop of the marcher (7 v_pk_* instructions of the ray generation + the
+// fine position's v_pk_fma) made 3 - 7 rays of 262 144 differ from launch to launch, always in lanes 48 - 63 of the coarse pass
+// (profiles/r4_render_spill.md; not root-caused - single-instruction hazards, modifiers, waits and scratch are excluded).  The library is built
+// with -fno-slp-vectorize; this fence additionally makes the tuple impossible whatever the flags (it is what turned that build green
+// in the bisect), and tests/test_render_gpu.py sweeps 100 scenes for bitwise repeatability.
+#define RAY_FENCE(o_, d_) asm volatile("" : "+v"((o_)[0]), "+v"((o_)[1]), "+v"((o_)[2]), "+v"((d_)[0]), "+v"((d_)[1]), "+v"((d_)[2]))
+
 // hidden index that accumulator register r of lane-half hi holds in hidden tile jt (MFMA 32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 // hi = fp32 truncated to bf16 (exact), lo = bf16(f - hi) (RNE): f ~ hi + lo to 2^-16 relative
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(64 * RENDER_WPB, RENDER_OCC) void render_kernel(Ren
     } else {
       make_ray(p.cams + 25 * v, p.res, pix, o, d);
     }
+    RAY_FENCE(o, d);
     const int grp = v / p.vpc;
     if (grp != cur_grp) {                                       // entering another call's rays: flush this wave's depth range
       flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);
@@ -758,6 +767,7 @@ __global__ __launch_bounds__(256, 1) void render_generic_kernel(RenderP p) {
     } else {
       make_ray(p.cams + 25 * v, p.res, pix, o, d);
     }
+    RAY_FENCE(o, d);
     const int grp = v / p.vpc;
     if (grp != cur_grp) {
       flush_depth_range(p.scal_u, cur_grp, dmin_l, dmax_l, lane);

@@ -212,3 +212,41 @@ def test_generic_marcher_agrees_with_the_lane_per_sample_kernel(hip_lib):
     assert torch.allclose(ss_a['coarse_coords'], ss_b['coarse_coords'], atol=1e-6)
     inb = ss_a['coarse_densities'] > -1e30
     assert torch.equal(inb, ss_b['coarse_densities'] > -1e30) and rel_l2(ss_b['coarse_densities'][inb], ss_a['coarse_densities'][inb]) < 1e-5
+
+
+def test_render_repeatability_sweep_100_scenes(hip_lib):
+    """r5: the launch-to-launch differences of the SLP build hit 3 - 7 rays of 262 144, scene-dependent
+    (profiles/r4_render_spill.md), so repeatability is swept over 100 random scenes - random tri-planes, camera radius 1.2 - 2.3,
+    elevation -30 ... +80 degrees, 1 - 6 views at 64^2 - 192^2, both marcher kernels (every fourth scene takes the generic one through
+    return_meta's outputs) - three launches each, identical bits."""
+    from ln3diff_amd.nsr.triplane import Triplane
+    from ln3diff_amd.synth import orbit_cameras
+    from oracle import render as orender
+    tp = Triplane(img_resolution=128)
+    tp.decoder.load_state_dict(_decoder_sd(4.0))
+    tp = tp.cuda()
+    rng = np.random.RandomState(7)
+    rays = 0
+    for scene in range(100):
+        V, res = int(rng.randint(1, 7)), int(rng.choice([64, 96, 128, 192]))
+        rad, el = float(rng.uniform(1.2, 2.3)), float(rng.uniform(-30.0, 80.0))
+        g = torch.Generator(device='cuda').manual_seed(1000 + scene)
+        pcl = torch.randn(1, 3, 128, 128, 32, device='cuda', generator=g) * float(rng.uniform(1.0, 5.0))
+        cams = orbit_cameras(V, radius=rad, elevation_deg=el).cuda()
+        j = torch.rand(V, res * res, 64, device='cuda', generator=g)
+        u = torch.rand(V * res * res, 64, device='cuda', generator=g)
+        idx = torch.zeros(V, dtype=torch.int32, device='cuda')
+        rays += V * res * res
+        if scene % 4 == 3:
+            ro, rd = (t.cuda() for t in orender.make_rays(cams.cpu(), res))
+            f = lambda: tp.renderer(None, tp.decoder, ro, rd, tp.rendering_kwargs, True, jitter=j, u_fine=u, planes_channel_last=pcl, plane_index=idx)
+            keys = ('feature_samples', 'depth_samples', 'weights_samples', 'visibility', 'weights')
+        else:
+            f = lambda: tp(c=cams, planes_channel_last=pcl, plane_index=idx, neural_rendering_resolution=res, jitter=j, u_fine=u)
+            keys = ('image_raw', 'image_depth', 'weights_samples')
+        ref = f()
+        for _ in range(2):
+            o = f()
+            for k in keys:
+                assert torch.equal(ref[k], o[k]), (scene, V, res, rad, el, k, int((ref[k] != o[k]).sum()))
+    print('repeatability sweep: 100 scenes, %.1f M rays x 3 launches, 0 differing values' % (rays / 1e6))
