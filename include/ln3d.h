@@ -335,6 +335,31 @@ int ln3d_groupnorm_swish(const float* x, const float* w, const float* b, void* y
  * (ldm model.py:54-70): out bf16 [N*Ho*Wo, Kpad], column = (ky*3+kx)*C + c, zero padded to Kpad             */
 int ln3d_im2col3x3(const void* x_bf16, void* col_bf16, int N, int H, int W, int C, int upsample, int Kpad, void* stream);
 
+/* ---------------------------------------------------------------- U-Net denoiser pieces (ABI 9; csrc/unet_ops.hip)
+ * The ShapeNet / FFHQ entry point's denoiser (guided_diffusion/unet.py:427-791: ResBlock, Downsample / Upsample, AttentionBlock,
+ * ldm/modules/attention_compat.py SpatialTransformer) on channel-last activations [N, H*W, C]; convolutions and linears are
+ * ln3d_gemm_bf16 calls (3x3 through ln3d_im2col3x3 / ln3d_im2col3x3_strided), the rest is here.
+ * GroupNorm(groups, C) for any C % groups == 0 over x f32 [N, HW, C] -> bf16: y = act(GN(x + add_row[n]) * w + b), optionally
+ * modulated per sample before the activation, t * (1 + mod_scale[n]) + mod_shift[n]  (ResBlock: `h + emb_out` :272-273 /
+ * use_scale_shift_norm :267-271).  add_row / mod_* f32 [N, C] or NULL; swish = SiLU. */
+int ln3d_groupnorm_any(const float* x, const float* add_row, const float* w, const float* b, const float* mod_scale, const float* mod_shift,
+                       void* y_bf16, int N, int HW, int C, int groups, float eps, int swish, void* stream);
+/* im2col for 3x3 pad 1 convs with a stride (Downsample.op, unet.py:150-153): out bf16 [N*Ho*Wo, Kpad], Ho = (H - 1) / stride + 1 */
+int ln3d_im2col3x3_strided(const void* x_bf16, void* col_bf16, int N, int H, int W, int C, int stride, int Kpad, void* stream);
+/* GEGLU (attention_compat.py:45-53): x f32 [rows, 2 * inner] = [a | gate] -> bf16 [rows, inner] = a * gelu_erf(gate) */
+int ln3d_geglu(const float* x, void* y_bf16, int64_t rows, int inner, void* stream);
+/* softmax(scale q k^T) v at any head size <= 256 over <= 1024 keys: q [B, Nq, ldq], k [B, Nk, ldk], v [B, Nk, ldv] bf16 token-major
+ * (head h = columns [h * Dh, (h + 1) * Dh) of the given pointers), out bf16 [B, Nq, H * Dh]  (CrossAttention.forward,
+ * attention_compat.py:179-202; QKVAttentionLegacy, unet.py:371-389) */
+int ln3d_attention_small(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int Dh, int64_t ldq,
+                         int64_t ldk, int64_t ldv, float scale, void* stream);
+/* NCHW f32 -> channel-last bf16 [N, HW, Cpad] (channels >= C zero) and channel-last f32 [N, HW, C] -> NCHW f32 */
+int ln3d_nchw_to_cl_bf16(const float* x, void* y_bf16, int N, int C, int HW, int Cpad, void* stream);
+int ln3d_cl_to_nchw_f32(const float* x, float* y, int N, int C, int HW, void* stream);
+/* LSGM mixed prediction of an eps model (continuous_diffusion_utils.py:748-754, gaussian_diffusion.py:336-348), in place on eps
+ * (NCHW f32): eps <- (1 - s_c) * sqrt(1 - alpha_bar_t) * x + s_c * eps, s_c = sigmoid(mixing_logit[c]) */
+int ln3d_mix_prediction(float* eps, const float* x, const float* mixing_logit, float sqrt_one_minus_ab, int N, int C, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

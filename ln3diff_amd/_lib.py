@@ -16,6 +16,8 @@ SYMBOLS = [
     "ln3d_planes_to_channel_last", "ln3d_planes_to_nchw", "ln3d_render_triplane",
     "ln3d_query_points", "ln3d_groupnorm_swish", "ln3d_im2col3x3", "ln3d_patch_embed_triplane", "ln3d_tile_rows", "ln3d_add_table_rows", "ln3d_cfg_combine_dup", "ln3d_ddim_step", "ln3d_mesh_count", "ln3d_mesh_emit", "ln3d_mcubes_count", "ln3d_mcubes_emit", "ln3d_lincomb", "ln3d_err_ratio_sq", "ln3d_embed_tokens", "ln3d_layernorm_f32", "ln3d_vit_patchify", "ln3d_vit_assemble", "ln3d_image_preprocess", "ln3d_plucker_rays",
     "ln3d_device_cus", "ln3d_stream_create_cu_mask", "ln3d_stream_cu_count",
+    "ln3d_groupnorm_any", "ln3d_im2col3x3_strided", "ln3d_geglu", "ln3d_attention_small", "ln3d_nchw_to_cl_bf16", "ln3d_cl_to_nchw_f32",
+    "ln3d_mix_prediction",
 ]
 
 EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU, EPI_CROSS_ATTN = range(10)

@@ -302,3 +302,37 @@ def masked_stream(bits, device):
 
 def stream_cu_count(stream=None):
     return int(L.lib().ln3d_stream_cu_count(C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)))
+
+
+# ---------------------------------------------------------------- U-Net pieces (csrc/unet_ops.hip)
+def groupnorm_any(x, w, b, y, N, HW, Cc, groups=32, eps=1e-5, swish=True, add_row=None, mod_scale=None, mod_shift=None):
+    _chk_dev(x, y)
+    L.check(L.lib().ln3d_groupnorm_any(_p(x), _p(add_row), _p(w), _p(b), _p(mod_scale), _p(mod_shift), _p(y), N, HW, Cc, groups, C.c_float(eps),
+                                       int(swish), _stream()), "groupnorm_any")
+
+
+def im2col3x3_strided(x, col, N, H, W, Cc, stride, Kpad):
+    L.check(L.lib().ln3d_im2col3x3_strided(_p(x), _p(col), N, H, W, Cc, stride, Kpad, _stream()), "im2col3x3_strided")
+
+
+def geglu(x, y, rows, inner):
+    L.check(L.lib().ln3d_geglu(_p(x), _p(y), C.c_int64(rows), inner, _stream()), "geglu")
+
+
+def attention_small(q, k, v, out, B, H, Nq, Nk, Dh, ldq, ldk, ldv, scale):
+    """q / k / v: bf16 tensors (or views into wider projection outputs) whose data_ptr is column 0 of head 0; ld* = their row strides"""
+    _chk_dev(q, k, v, out)
+    L.check(L.lib().ln3d_attention_small(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, Dh, C.c_int64(ldq), C.c_int64(ldk), C.c_int64(ldv),
+                                         C.c_float(scale), _stream()), "attention_small")
+
+
+def nchw_to_cl_bf16(x, y, N, Cc, HW, Cpad):
+    L.check(L.lib().ln3d_nchw_to_cl_bf16(_p(x), _p(y), N, Cc, HW, Cpad, _stream()), "nchw_to_cl_bf16")
+
+
+def cl_to_nchw_f32(x, y, N, Cc, HW):
+    L.check(L.lib().ln3d_cl_to_nchw_f32(_p(x), _p(y), N, Cc, HW, _stream()), "cl_to_nchw_f32")
+
+
+def mix_prediction(eps, x, mixing_logit, sqrt_one_minus_ab, N, Cc, HW):
+    L.check(L.lib().ln3d_mix_prediction(_p(eps), _p(x), _p(mixing_logit), C.c_float(sqrt_one_minus_ab), N, Cc, HW, _stream()), "mix_prediction")

@@ -47,6 +47,13 @@ NULL_CALLS = {
     'ln3d_groupnorm_swish': (N, N, N, N, N, 1, 64, 64, 32, F(1e-6), 1, N),
     'ln3d_im2col3x3': (N, N, 1, 8, 8, 64, 1, 576, N),
     'ln3d_stream_create_cu_mask': (N, 1, N),
+    'ln3d_groupnorm_any': (N, N, N, N, N, N, N, 1, 16, 64, 32, F(1e-5), 1, N),
+    'ln3d_im2col3x3_strided': (N, N, 1, 8, 8, 64, 2, 576, N),
+    'ln3d_geglu': (N, N, I64(1), 64, N),
+    'ln3d_attention_small': (N, N, N, N, 1, 1, 16, 16, 40, I64(40), I64(40), I64(40), F(0.1), N),
+    'ln3d_nchw_to_cl_bf16': (N, N, 1, 12, 64, 16, N),
+    'ln3d_cl_to_nchw_f32': (N, N, 1, 12, 64, N),
+    'ln3d_mix_prediction': (N, N, N, F(0.5), 1, 12, 64, N),
 }
 NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_device_cus', 'ln3d_stream_cu_count'}      # pure host queries
 

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p build/v_$tag
 objs=""
-for f in gemm_bf16 attention dit_ops render conv_ops mesh runtime; do
+for f in gemm_bf16 attention dit_ops render conv_ops mesh runtime unet_ops; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC "$@" -c ln3diff_amd/csrc/$f.hip -o build/v_$tag/$f.o &
   objs="$objs build/v_$tag/$f.o"
 done
