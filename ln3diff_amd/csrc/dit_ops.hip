@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(NormP p) {
 }
 
 extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
-  if (!a || !a->x || !a->y || a->D % 128 != 0 || a->D > 128 * MAXV || a->rows <= 0) return LN3D_ERR_BAD_ARG;
+  constexpr int MVG = (128 * MAXV + 511) / 512;                   // 512-feature chunks per lane set: widths up to 1536 (the U-Net's 1280)
+  if (!a || !a->x || !a->y || a->D % 128 != 0 || a->D > 512 * MVG || a->rows <= 0) return LN3D_ERR_BAD_ARG;
   if ((a->scale == nullptr) != (a->shift == nullptr)) return LN3D_ERR_BAD_ARG;
   if (a->scale && (a->mod_ld % 4) != 0) return LN3D_ERR_BAD_ARG;                       // 16-byte modulation quads
   if ((a->scale_table == nullptr) != (a->shift_table == nullptr)) return LN3D_ERR_BAD_ARG;
@@ -116,7 +117,6 @@ extern "C" int ln3d_norm_modulate(const ln3d_norm_args* a, void* stream) {
   p.shift_table = a->shift_table; p.scale_table = a->scale_table;
   p.rows_in = a->rows_in > 0 ? a->rows_in : (int)a->rows; p.rows_out = a->rows_out > 0 ? a->rows_out : p.rows_in;
   const dim3 grid((unsigned)((a->rows + 3) / 4));
-  constexpr int MVG = (128 * MAXV + 511) / 512;
   if (a->D % 512 == 0 && a->D <= 1024) hipLaunchKernelGGL((norm_modulate_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
   else if (a->D % 512 == 0) hipLaunchKernelGGL((norm_modulate_kernel<MVG, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((norm_modulate_kernel<MVG, false>), grid, dim3(256), 0, (hipStream_t)stream, p);

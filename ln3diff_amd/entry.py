@@ -35,7 +35,7 @@ _IGNORED_DEFAULTS = dict(lr=5e-5, batch_size=1, microbatch=-1, ema_rate='0.9999'
 # sampled.  (name: (default, {allowed values} or None = any, engines it matters for, message))
 _RELEASED_DECODER = 'vit.vit_triplane.RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder'
 _CHECKED = {
-    'mixed_prediction': (False, {False}, ('edm', 'flow', 'gd'), "the mixing-component denoiser output (LSGM mixed prediction) is not built"),
+    'mixed_prediction': (False, None, ('edm', 'flow', 'gd'), None),      # see validate(): the U-Net denoiser (--create_dit false) has it
     'predict_v': (False, None, ('gd',), None),            # see validate(): only the guided_diffusion engines read them
     'pred_type': ('eps', None, ('gd',), None),            # (guided_diffusion/script_util.py:36-37,84,682-686: predict_v -> ModelMeanType.V)
     'ae_classname': (_RELEASED_DECODER, {_RELEASED_DECODER}, ('edm', 'flow', 'gd'), "only the released decoder class is built"),
@@ -76,7 +76,11 @@ def create_argparser(objaverse=True):
         cond_path='', pose_path='', seed=41 if objaverse else 0, context_dim=768, learn_sigma=False, denoise_in_channels=4,
         diffusion_input_size=32, roll_out=True, prompt=None, cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
         mv_input=False, num_mv_views=4, mv_dino_arch='vitl', clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
-        overwrite_diff_inp_size='', create_controlnet=False)
+        overwrite_diff_inp_size='', create_controlnet=False,
+        # the U-Net denoiser of the ShapeNet / FFHQ launchers (guided_diffusion/script_util.py create_model, --create_dit False there)
+        create_dit=True, num_channels=320, num_res_blocks=2, channel_mult='', attention_resolutions='4,2,1', num_heads=8,
+        num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=True, use_spatial_transformer=True, transformer_depth=1,
+        dropout=0.0, mixing_logit_init=-6.0)
     d.update(_IGNORED_DEFAULTS)
     d.update({k: v[0] for k, v in _CHECKED.items()})
     ap = argparse.ArgumentParser(allow_abbrev=False)
@@ -95,12 +99,18 @@ def validate(args):
     kind = TRAINERS[args.trainer_name]
     if args.create_controlnet or 'cldm' in args.trainer_name:
         raise SystemExit("ControlNet engines are outside the sampling hot path (SURVEY.md section 8)")
+    unet = not args.create_dit
+    if unet and kind != 'gd':
+        raise SystemExit("--create_dit false (the U-Net denoiser) runs under the guided_diffusion engines: --trainer_name adm / ddpm / vpsde_crossattn")
+    if args.mixed_prediction and not unet:
+        raise SystemExit("--mixed_prediction true: only the U-Net denoiser (--create_dit false) defines a mixing_logit (the reference's DiT "
+                         "classes have it commented out, dit/dit_models_xformers.py:767-772)")
     reg = I23D if args.i23d else T23D
-    if args.dit_model_arch not in reg:
+    if not unet and args.dit_model_arch not in reg:
         other = T23D if args.i23d else I23D
         hint = " (that is an %s architecture: %s --i23d)" % (("T23D", "drop") if args.i23d else ("I23D", "pass")) if args.dit_model_arch in other else ""
         raise SystemExit(f"--dit_model_arch {args.dit_model_arch}: not in the {'I23D' if args.i23d else 'T23D'} registry {sorted(reg)}{hint}; "
-                         "U-Net denoisers are outside the hot path")
+                         "the U-Net denoiser is --create_dit false")
     if args.arch_dit_decoder not in DiT2_models:
         raise SystemExit(f"--arch_dit_decoder {args.arch_dit_decoder}: known {sorted(DiT2_models)}")
     pixart_t23d = (not args.i23d) and args.dit_model_arch.startswith('DiT-PixelArt')
@@ -128,7 +138,10 @@ def validate(args):
     if args.denoise_out_channels != args.denoise_in_channels:
         raise SystemExit(f"--denoise_out_channels {args.denoise_out_channels} != --denoise_in_channels {args.denoise_in_channels}: the "
                          "samplers update the latent in place with the network output (learn_sigma False)")
-    if kind == 'gd' and (args.predict_v or args.pred_type not in ('eps', 'epsilon')):
+    if unet and (args.predict_v or args.pred_type == 'v') and not args.mixed_prediction:
+        raise SystemExit("--predict_v true with the U-Net needs --mixed_prediction true: the reference's p_mean_variance only converts v to "
+                         "eps inside its mixing branch (guided_diffusion/gaussian_diffusion.py:327-343, :399-400 asserts it)")
+    if kind == 'gd' and not unet and (args.predict_v or args.pred_type not in ('eps', 'epsilon')):
         # create_gaussian_diffusion maps --predict_v to ModelMeanType.V (guided_diffusion/script_util.py:682-686); the guided_diffusion
         # engines of this build implement ModelMeanType.EPSILON.  (The released Objaverse launchers pass --predict_v True --pred_type v
         # but run the sgm / flow-matching engines, which never read them - accepted there.)
@@ -153,7 +166,22 @@ def build_models(args, dev, rank):
     from .checkpoint import load_checkpoint
     common = dict(input_size=args.diffusion_input_size, num_classes=0, learn_sigma=args.learn_sigma,
                   in_channels=args.denoise_in_channels, roll_out=args.roll_out)
-    if args.i23d:
+    if not args.create_dit:
+        # guided_diffusion/script_util.py:255-451 create_model, U-Net branch (the ShapeNet / FFHQ launchers): the released VAE decoder of
+        # those launchers (ViT-B decoder + 32-channel renderer + NearestConvSR) is not built - the latent is decoded by the released
+        # Objaverse decoder class like every other denoiser's here
+        from .guided_diffusion.unet import create_unet
+        dit = create_unet(args.diffusion_input_size, args.num_channels, args.num_res_blocks, channel_mult=args.channel_mult,
+                          learn_sigma=args.learn_sigma, attention_resolutions=args.attention_resolutions, num_heads=args.num_heads,
+                          num_head_channels=args.num_head_channels, num_heads_upsample=args.num_heads_upsample,
+                          use_scale_shift_norm=args.use_scale_shift_norm, dropout=args.dropout,
+                          denoise_in_channels=args.denoise_in_channels, denoise_out_channels=args.denoise_out_channels,
+                          mixed_prediction=args.mixed_prediction,
+                          use_spatial_transformer=args.use_spatial_transformer, transformer_depth=args.transformer_depth,
+                          context_dim=args.context_dim if args.use_spatial_transformer else None, mixing_logit_init=args.mixing_logit_init,
+                          roll_out=args.roll_out)
+        dit.embed_dim = {'DiT2-B/2': 768, 'DiT2-L/2': 1024, 'DiT2-XL/2': 1152}.get(args.arch_dit_decoder, 1024)     # the decoder tokeniser's width
+    elif args.i23d:
         # multi-view denoisers cross-attend to the raw multi-view DINO tokens: their context width is the conditioner tower's
         # (--mv_dino_arch: vitl 1024, the released mv23d-plucker configs' vitb 768)
         ctx_dim = _MV_DINO_WIDTH[args.mv_dino_arch] if args.mv_input else 1024
@@ -375,8 +403,10 @@ def run(args, objaverse=None):
         spec = args.timestep_respacing or str(args.diffusion_steps)
         if args.use_ddim and not spec.startswith('ddim'):
             spec = 'ddim' + spec
+        v_pred = (not args.create_dit) and (args.predict_v or args.pred_type == 'v')          # create_gaussian_diffusion: predict_v -> ModelMeanType.V
         diff = SpacedDiffusion(use_timesteps=space_timesteps(args.diffusion_steps, spec),
-                               betas=gd.get_named_beta_schedule(args.noise_schedule, args.diffusion_steps))
+                               betas=gd.get_named_beta_schedule(args.noise_schedule, args.diffusion_steps),
+                               model_mean_type=gd.ModelMeanType.V if v_pred else gd.ModelMeanType.EPSILON)
         eng = GuidedDiffusionEngine(dit, ae, diff, triplane_scaling_divider=args.triplane_scaling_divider, img_size=args.image_size,
                                     diffusion_input_size=S)
 

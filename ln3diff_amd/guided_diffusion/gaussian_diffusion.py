@@ -34,8 +34,9 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
 class GaussianDiffusion:
     def __init__(self, *, betas, model_mean_type=ModelMeanType.EPSILON, model_var_type=ModelVarType.FIXED_LARGE,
                  loss_type=None, rescale_timesteps=False, **_):
-        assert model_mean_type == ModelMeanType.EPSILON and model_var_type == ModelVarType.FIXED_LARGE, \
-            "sampling path of the DiT checkpoints: eps-prediction, fixed-large variance"
+        assert model_mean_type in (ModelMeanType.EPSILON, ModelMeanType.V) and model_var_type == ModelVarType.FIXED_LARGE, \
+            "sampling paths of the released checkpoints: eps-prediction (DiT) or v-prediction with mixed prediction (ShapeNet U-Net), fixed-large variance"
+        self.model_mean_type = model_mean_type
         b = self.betas = np.array(betas, dtype=np.float64)
         self.num_timesteps = int(b.shape[0])
         alphas = 1.0 - b
@@ -53,26 +54,48 @@ class GaussianDiffusion:
     def _model_t(self, i):
         return float(i)
 
+    def _generic_eps(self, net, x_in, t_dev, ctx, i, mixing_normal):
+        """The network output of a denoiser without the DiT's context cache (the U-Net), brought to eps as p_mean_variance does
+        (gaussian_diffusion.py:327-348): v-prediction -> eps = sqrt(ab) v + sqrt(1 - ab) x (:451-455), then the LSGM mixed prediction
+        (1 - s) sqrt(1 - ab) x + s eps with the model's own mixing_logit (mixing_normal)."""
+        out = net(x_in, t_dev, context=ctx).contiguous()
+        ab = np.float32(self.alphas_cumprod[i])
+        s1m = float(np.sqrt(np.float32(1) - ab))
+        if self.model_mean_type == ModelMeanType.V:
+            eps = torch.empty_like(out)
+            ops.lincomb(None, [out, x_in.contiguous().float()], [float(np.sqrt(ab)), s1m], eps)
+        else:
+            eps = out
+        if mixing_normal:
+            net.mix(eps, x_in, s1m)
+        return eps
+
     @torch.no_grad()
     def p_sample_loop(self, model, shape, cond=None, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, mixing_normal=False, step_noise=None, trace=None):
         """model: object with apply_model_inference(x, t, c) (the engines' contract, respace.py:136) or a DiT.
         step_noise: optional callable k -> randn tensor for loop iteration k (parity runs feed the recorded stream);
         default draws torch.randn on the device."""
-        assert not mixing_normal and denoised_fn is None and cond_fn is None
+        assert denoised_fn is None and cond_fn is None
         dev = torch.device(device) if device is not None else noise.device
         x = noise.to(dev).float().clone() if noise is not None else torch.randn(*shape, device=dev)
         B = shape[0]
         call = model.apply_model_inference if hasattr(model, 'apply_model_inference') else (lambda a, t, c, **k: model(a, t, c, **k))
         cache = None
         net = getattr(model, 'ddp_model', model)
-        if hasattr(net, 'prepare_context') and cond is not None:
+        generic = not hasattr(net, 'prepare_context')           # the U-Net: no per-prompt context cache, v-prediction / mixing handled here
+        assert generic or (not mixing_normal and self.model_mean_type == ModelMeanType.EPSILON), \
+            "mixing_normal / v-prediction belong to the U-Net denoiser (the reference's DiT classes define no mixing_logit)"
+        if not generic and cond is not None:
             cache = net.prepare_context(cond.to(dev) if torch.is_tensor(cond) else cond)
         t_dev = torch.empty(B, device=dev, dtype=torch.float32)
         fl = np.log(np.append(self.posterior_variance[1], self.betas[1:]))
         for k, i in enumerate(range(self.num_timesteps)[::-1]):
             t_dev.fill_(self._model_t(i))
-            eps = call(x, t_dev, cond, context_cache=cache) if cache is not None else call(x, t_dev, cond)
+            if generic:
+                eps = self._generic_eps(net, x, t_dev, cond, i, mixing_normal)
+            else:
+                eps = call(x, t_dev, cond, context_cache=cache) if cache is not None else call(x, t_dev, cond)
             z = step_noise(k).to(dev) if step_noise is not None else torch.randn(x.shape, device=dev)
             f = lambda a: float(np.float32(a[i]))
             sig = float(np.exp(np.float32(0.5) * np.float32(fl[i]))) if i != 0 else 0.0
@@ -91,13 +114,15 @@ class GaussianDiffusion:
                          step_noise=None, trace=None):
         """DDIM (reference :729-866,908-1000).  cond: tensor or {'c_crossattn': tensor}; CFG batches [uncond ; cond]
         (uncond = zeros unless given) and combines eps."""
-        assert not mixing_normal and denoised_fn is None and cond_fn is None
+        assert denoised_fn is None and cond_fn is None
         dev = torch.device(device) if device is not None else noise.device
         x = noise.to(dev).float().clone() if noise is not None else torch.randn(*shape, device=dev)
         B = shape[0]
         c = cond['c_crossattn'] if isinstance(cond, dict) else cond
         cfg = unconditional_guidance_scale != 1.0
         net = getattr(model, 'ddp_model', model)
+        generic = not hasattr(net, 'prepare_context')
+        assert generic or (not mixing_normal and self.model_mean_type == ModelMeanType.EPSILON)
         if cfg:
             ucond = torch.zeros_like(c) if unconditional_conditioning is None else unconditional_conditioning
             if ucond.shape[0] != B:
@@ -106,12 +131,15 @@ class GaussianDiffusion:
         else:
             ctx = c.to(dev)
         nb = ctx.shape[0]
-        cache = net.prepare_context(ctx)
+        cache = None if generic else net.prepare_context(ctx)
         t_dev = torch.empty(nb, device=dev, dtype=torch.float32)
         f32 = lambda v: float(np.float32(v))
         for k, i in enumerate(range(self.num_timesteps)[::-1]):
             t_dev.fill_(self._model_t(i))
-            eps = net(x, t_dev, context_cache=cache)                    # [nb, ...] on x replicated b % B
+            if generic:                                                # x_in = cat([x] * 2) under CFG (gaussian_diffusion.py:811-812)
+                eps = self._generic_eps(net, torch.cat([x, x]) if cfg else x, t_dev, ctx, i, mixing_normal)
+            else:
+                eps = net(x, t_dev, context_cache=cache)                # [nb, ...] on x replicated b % B
             ab, abp = np.float32(self.alphas_cumprod[i]), np.float32(self.alphas_cumprod_prev[i])
             sig = np.float32(eta) * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
             coef = np.sqrt(np.float32(1) - abp - sig ** 2)

@@ -248,7 +248,8 @@ class GuidedDiffusionEngine:
     (nsr/lsgm/crossattn_cldm.py:510-640): `SpacedDiffusion.p_sample_loop` - or `ddim_sample_loop` with classifier-free guidance
     when use_ddim - over the denoiser, then render_video_given_triplane per sample.  The reference passes mixing_normal=True,
     which reads `ddpm_model.mixing_logit`; its DiT classes do not define one (dit/dit_models_xformers.py:767-772 is commented
-    out), so that branch only ever ran with the U-Net denoiser, which is outside the hot path: mixing is off here."""
+    out), so that branch only ever ran with the U-Net denoiser (ln3diff_amd.guided_diffusion.unet.UNetModel, r5): mixing is applied
+    for a denoiser built with mixed_prediction, and is off for the DiTs."""
 
     def __init__(self, ddpm_model, decoder, diffusion, conditioner=None, triplane_scaling_divider=1.0, img_size=128, batch_size=1,
                  diffusion_input_size=32):
@@ -276,10 +277,14 @@ class GuidedDiffusionEngine:
             c = None
         if noise is None:
             noise = torch.randn(*shape, device=device)
+        # mixing_normal=True as the reference passes it (crossattn_cldm.py:543-547, train_util_diffusion.py:888): read by the denoiser
+        # that HAS a mixing_logit - the U-Net with mixed_prediction; the DiT classes define none (see the class docstring)
+        mix = bool(getattr(self.ddpm_model, 'mixed_prediction', False)) and hasattr(self.ddpm_model, 'mix')
         if use_ddim:
             return self.diffusion.ddim_sample_loop(self.ddpm_model, shape, cond=c, noise=noise, clip_denoised=clip_denoised,
-                                                   unconditional_guidance_scale=unconditional_guidance_scale, device=device)
-        return self.diffusion.p_sample_loop(self.ddpm_model, shape, cond=c, noise=noise, clip_denoised=clip_denoised, device=device)
+                                                   unconditional_guidance_scale=unconditional_guidance_scale, device=device, mixing_normal=mix)
+        return self.diffusion.p_sample_loop(self.ddpm_model, shape, cond=c, noise=noise, clip_denoised=clip_denoised, device=device,
+                                            mixing_normal=mix)
 
     @torch.no_grad()
     def eval_cldm(self, cond, camera, use_ddim=False, unconditional_guidance_scale=1.0, export_mesh=False, resolution=None,

@@ -174,9 +174,11 @@ def ddpm_p_sample_loop(net, x, noises, cond, tables, clip_denoised=False, trace=
     return x
 
 
-def ddim_sample_loop(net, x, cond, tables, eta=0.0, cfg_scale=1.0, ucond=None, noises=None, clip_denoised=False, trace=None):
+def ddim_sample_loop(net, x, cond, tables, eta=0.0, cfg_scale=1.0, ucond=None, noises=None, clip_denoised=False, trace=None, to_eps=None):
     """GaussianDiffusion.ddim_sample_loop, non-objv branch (gaussian_diffusion.py:729-866,908-1000): CFG batch is
-    [uncond ; cond]; eps is re-derived from pred_xstart; sigma from eta; `noises[k]` = randn_like of loop iteration k."""
+    [uncond ; cond]; eps is re-derived from pred_xstart; sigma from eta; `noises[k]` = randn_like of loop iteration k.
+    to_eps(out, x_in, t_idx): what p_mean_variance does to the raw network output before it is an eps (:327-348: v-prediction ->
+    eps, LSGM mixed prediction with the model's mixing_logit) - the U-Net path; None = the network predicts eps."""
     B = x.shape[0]
     tmap = torch.tensor(tables.timestep_map)
     acp = np.append(1.0, tables.alphas_cumprod[:-1])
@@ -185,6 +187,8 @@ def ddim_sample_loop(net, x, cond, tables, eta=0.0, cfg_scale=1.0, ucond=None, n
         def x0_eps(xin, tin, c):
             tc = tmap[tin] / tables.original_num_steps
             e = net(xin, tc, c)
+            if to_eps is not None:
+                e = to_eps(e, xin, tin)
             x0 = (_extract(tables.sqrt_recip_alphas_cumprod, tin, xin.shape) * xin -
                   _extract(tables.sqrt_recipm1_alphas_cumprod, tin, xin.shape) * e)
             if clip_denoised:

@@ -367,7 +367,8 @@ SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim'
 
 if __name__ == '__main__':
     from make_golden_render import sec_render, sec_decoder, sec_render_presets   # noqa: E402
-    SECTIONS.update(render=sec_render, decoder=sec_decoder, render_presets=sec_render_presets)
+    from make_golden_unet import sec_unet   # noqa: E402
+    SECTIONS.update(render=sec_render, decoder=sec_decoder, render_presets=sec_render_presets, unet=sec_unet)
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
         t0 = time.time()

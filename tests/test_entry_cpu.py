@@ -51,7 +51,8 @@ def test_registry_is_chosen_by_the_i23d_flag():
 
 
 @pytest.mark.parametrize("flags,msg", [
-    (("--mixed_prediction", "True"), "mixed prediction"),
+    (("--mixed_prediction", "True"), "only the U-Net denoiser"),
+    (("--create_dit", "false"), "guided_diffusion engines"),
     (("--ae_classname", "vit.vit_triplane.SomethingElse"), "released decoder class"),
     (("--vae_p", "4"), "vae_p = 2"),
     (("--denoise_out_channels", "8"), "denoise_out_channels"),
@@ -72,9 +73,18 @@ def test_released_launcher_values_of_checked_flags_pass():
               "--denoise_out_channels", "4", "--decoder_in_chans", "32", "--out_chans", "96", "--triplane_in_chans", "32", "--decoder_output_dim", "3",
               "--ae_classname", "vit.vit_triplane.RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder")
     assert validate(a) == 'edm'                     # the sgm engine never reads predict_v / pred_type (the reference neither)
-    with pytest.raises(SystemExit) as e:            # ... the guided_diffusion engines do: ModelMeanType.V is not built
+    with pytest.raises(SystemExit) as e:            # ... the guided_diffusion engines do: ModelMeanType.V belongs to the U-Net denoiser
         validate(_args(False, "--predict_v", "True"))
     assert "epsilon only" in str(e.value)
+    # sample_shapenet_*_t23d.sh: the U-Net, v-prediction with mixed prediction, DDIM 250
+    shapenet = ("--create_dit", "false", "--trainer_name", "vpsde_crossattn", "--num_channels", "320", "--num_res_blocks", "2", "--num_heads", "8",
+                "--attention_resolutions", "4,2,1", "--use_spatial_transformer", "True", "--transformer_depth", "1", "--context_dim", "768",
+                "--denoise_in_channels", "12", "--denoise_out_channels", "12", "--roll_out", "false", "--predict_v", "True", "--pred_type", "v",
+                "--mixed_prediction", "True", "--use_ddim", "True", "--timestep_respacing", "ddim250")
+    assert validate(_args(False, *shapenet)) == 'gd'
+    with pytest.raises(SystemExit) as e:            # v-prediction without the mixing branch: the reference's p_mean_variance asserts
+        validate(_args(False, *[("False" if f == "True" and shapenet[i - 1] == "--mixed_prediction" else f) for i, f in enumerate(shapenet)]))
+    assert "needs --mixed_prediction" in str(e.value)
 
 
 def test_conditioning_is_never_silently_synthetic():
