@@ -28,19 +28,19 @@ def _sha16(rel):
 
 
 def pmc_traffic(key):
-    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r4_pmc.json:
+    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r5_pmc.json:
     FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes; bench.py cannot run the profiler on itself).  An entry is
     only valid for the kernel source it was measured on: it carries the sha256 of the .hip file, and a different source on disk
     yields null plus the reason instead of a stale number."""
-    path = os.path.join(ROOT, 'profiles', 'r4_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r5_pmc.json')
     if not os.path.exists(path):
-        return None, 'profiles/r4_pmc.json missing'
+        return None, 'profiles/r5_pmc.json missing'
     ent = json.load(open(path)).get(key)
     if ent is None:
-        return None, 'no PMC entry for %s in profiles/r4_pmc.json' % key
+        return None, 'no PMC entry for %s in profiles/r5_pmc.json' % key
     cur = _sha16(ent['hip'])
     if cur != ent['sha16']:
-        return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/pmc_traffic.sh' % (ent['hip'], cur, ent['sha16'])
+        return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/r5_pmc.sh' % (ent['hip'], cur, ent['sha16'])
     return ent['traffic_bytes'], ent['source']
 
 
@@ -122,8 +122,8 @@ def gate_res_probe(dev, n_net, D, iters=20, tokens=768):
     ach = flops / (ms * 1e-3) / 1e12
     return {"kernel": "gemm_bf16_ring64_kernel<GATE_RES, 256x192> (DiT MLP fc2: gate * out + residual into the fp32 stream)", "shape": [M, N, K],
             "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2),
-            "traffic": None, "traffic_source": "no PMC pass for this kernel (algorithmic bytes: X %d MB + W %d MB read, %d MB residual read + written)"
-            % (M * K * 2 // 2 ** 20, N * K * 2 // 2 ** 20, M * N * 8 // 2 ** 20)}
+            "traffic": pmc_traffic("gemm_fc2_gateres_%dx%dx%d" % (M, N, K))[0], "traffic_source": pmc_traffic("gemm_fc2_gateres_%dx%dx%d" % (M, N, K))[1],
+            "algorithmic_bytes": "X %d MB + W %d MB read, %d MB residual read + written" % (M * K * 2 // 2 ** 20, N * K * 2 // 2 ** 20, M * N * 8 // 2 ** 20)}
 
 
 def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
@@ -158,10 +158,22 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
             "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": traffic, "traffic_source": src}
 
 
+def pmc_entry(key):
+    """The whole committed PMC record of a kernel (profiles/r5_pmc.json), or None when absent / measured on another source."""
+    path = os.path.join(ROOT, 'profiles', 'r5_pmc.json')
+    if not os.path.exists(path):
+        return None
+    ent = json.load(open(path)).get(key)
+    return ent if ent is not None and _sha16(ent['hip']) == ent['sha16'] else None
+
+
 def render_probe(dev, dec, res=256, V=4, iters=5):
-    """The fused ray-marcher is NOT an HBM-streaming kernel (the 6 MB tri-plane is L2-resident, profiles/r2_render_pmc.md): the
-    honest figures are ms/view against SURVEY.md 8d's 2.7 ms HBM-gather target, the MFMA fraction of its decoder MLP, and the
-    PMC HBM bytes.  `achieved`/`frac` keep the contract's algorithmic-gather-bytes definition for continuity."""
+    """The fused ray-marcher.  It is NOT an HBM-streaming kernel: one tri-plane is 6 MB and stays in L2 (fabric traffic ~100 MB per
+    256^2 view against 12.9 GB of gathered texel bytes), so SURVEY 8d's "gather bytes / HBM peak" is not a roofline for it (r1 - r4
+    printed that ratio as frac = 2.2).  What bounds it is vector-instruction issue: `bound` = "valu-issue", `frac` = the SIMDs'
+    VALU-busy cycles / elapsed cycles from the committed counter pass (SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs),
+    profiles/r5_pmc.json, tools/r5_pmc.sh), `achieved` / `peak` = vector instructions per second issued / issuable (1024 SIMDs x
+    clock / 4 cycles per wave64 instruction at the measured clock).  The texel-gather rate is kept as l2_gather_GBps."""
     from ln3diff_amd.synth import orbit_cameras
     tp = dec.triplane_decoder
     pcl = torch.randn(1, 3, 128, 128, 32, device=dev) * 4.0
@@ -178,15 +190,24 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     pts = V * res * res * 128
-    gbytes = pts * 1536.0 / 1e9                    # SURVEY.md §8d: 3 planes x 4 taps x 32 ch x 4 B per sample point
-    ach = gbytes / (ms * 1e-3)
+    gbytes = pts * 1536.0 / 1e9                    # SURVEY.md 8d: 3 planes x 4 taps x 32 ch x 4 B per sample point
     mlp_tflops = pts * 2.0 * (32 * 64 + 64 * 4) * 3 / (ms * 1e-3) / 1e12      # bf16x3 split: 3 MFMA products per fp32 product
-    return {"kernel": "render_kernel (fused tri-plane ray-march, %dx%d^2 views)" % (V, res), "bound": "hbm",
-            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-            "definition": "algorithmic gather bytes (1536 B/sample point) / time; the texels are L2-resident so this is an L2-gather "
-                          "rate, not HBM traffic - judge the kernel on ms_per_view vs target_ms_per_view",
-            "ms_per_view": round(ms / V, 3), "target_ms_per_view": 2.7, "mlp_issued_bf16_tflops": round(mlp_tflops, 1),
-            "traffic": pmc_traffic("render_%dx%d" % (V, res))[0], "traffic_source": pmc_traffic("render_%dx%d" % (V, res))[1]}
+    rec = {"kernel": "render_kernel (fused tri-plane ray-march, %dx%d^2 views)" % (V, res), "bound": "valu-issue", "unit": "G vector instructions/s",
+           "ms_per_view": round(ms / V, 3), "target_ms_per_view": 2.7, "l2_gather_GBps": round(gbytes / (ms * 1e-3), 1),
+           "mlp_issued_bf16_tflops": round(mlp_tflops, 1),
+           "traffic": pmc_traffic("render_%dx%d" % (V, res))[0], "traffic_source": pmc_traffic("render_%dx%d" % (V, res))[1]}
+    ent = pmc_entry("render_%dx%d" % (V, res))
+    if ent and ent.get("issue"):
+        iss = ent["issue"]
+        clock_ghz = iss["cycles_per_launch"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0          # counter cycles over this run's launch time
+        rec.update({"achieved": round(iss["valu_insts"] / (ms * 1e-3) / 1e9, 1), "peak": round(1024 * clock_ghz / 4, 1),
+                    "frac": round(iss["valu_busy_frac"], 4), "valu_insts_per_ray": round(iss["valu_insts"] / (V * res * res), 0),
+                    "mfma_busy_frac": round(iss["mfma_busy_frac"], 4), "lds_busy_frac": round(iss["lds_busy_frac"], 4),
+                    "issue_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (tools/r5_pmc.sh; "
+                                    "quad-cycle counters x 4, 1024 SIMDs); frac = VALU-busy SIMD cycles / elapsed SIMD cycles"})
+    else:
+        rec.update({"achieved": None, "peak": None, "frac": None, "issue_source": "no counter pass for this source (profiles/r5_pmc.json): tools/r5_pmc.sh"})
+    return rec
 
 
 def _pick_threads():

@@ -1,5 +1,5 @@
 """One kernel at one shape, launched 3 times - the target of the rocprofv3 --pmc passes of tools/pmc_traffic.sh.
-usage: pmc_one.py gemm M N K | attn BH Nq Nk Dh | render V RES"""
+usage: pmc_one.py gemm M N K | gemm_gr M N K | attn BH Nq Nk Dh | render V RES"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ln3diff_amd import ops
@@ -13,6 +13,15 @@ if which == 'gemm':
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     for _ in range(3):
         ops.gemm(x, w, b, ops.EPI_GELU_ERF, out)
+elif which == 'gemm_gr':                      # fc2: gate * out + residual into the fp32 stream (the kernel NAME with the largest share of a step)
+    M, N, K = a
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) * 0.02
+    res = torch.randn(M, N, device=dev)
+    gate = torch.randn(M // 768, 6 * N, device=dev) * 0.1
+    for _ in range(3):
+        ops.gemm(x, w, b, ops.EPI_GATE_RES, res, None, gate=gate, gate_rows=768, gate_ld=6 * N)
 elif which == 'attn':
     BH, Nq, Nk, Dh = a
     H = 16
