@@ -44,7 +44,7 @@ _CHECKED = {
     'decoder_in_chans': (32, {32}, ('edm', 'flow', 'gd'), "tri-plane feature width 32 (OSGDecoder 32 -> 64 -> 4)"),
     'triplane_in_chans': (32, {32}, ('edm', 'flow', 'gd'), "tri-plane feature width 32"),
     'out_chans': (96, {96}, ('edm', 'flow', 'gd'), "3 planes x 32 channels"),
-    'decoder_output_dim': (3, {3}, ('edm', 'flow', 'gd'), "RGB output"),
+    'decoder_output_dim': (3, {3, 32}, ('edm', 'flow', 'gd'), "3 (Objaverse) or 32 (ShapeNet / FFHQ launchers; without the SR module only its first 3 colours are rendered)"),
     'patch_size': (14, None, (), None),                   # the VAE *encoder's* ViT patch size (DINO 14): encoder only, unused here
 }
 

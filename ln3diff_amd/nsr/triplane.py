@@ -24,13 +24,19 @@ class FullyConnectedLayer(nn.Module):      # nsr/networks_stylegan2.py:122-157 (
 
 
 class OSGDecoder(nn.Module):               # nsr/triplane.py:339-372
+    """32 -> 64 -> 1 + decoder_output_dim.  The Objaverse configurations use decoder_output_dim = 3; the ShapeNet / FFHQ launchers 32
+    (`--decoder_output_dim 32`): their extra 29 colour channels only feed the super-resolution module, which no released sampler
+    instantiates (every launcher passes --sr_training False, so sr_kwargs = {} and Triplane.superresolution is None:
+    scripts/vit_triplane_diffusion_sample.py:83-90, nsr/triplane.py:476-500) - `image_raw = feature_image[:, :3]` (nsr/triplane.py:683).
+    The kernels therefore evaluate output rows 0 - 3 (sigma, r, g, b) of whatever width the module holds."""
+
     def __init__(self, n_features=32, options=None):
         super().__init__()
         options = options or {'decoder_lr_mul': 1, 'decoder_output_dim': 3}
         assert options.get('decoder_lr_mul', 1) == 1
         self.hidden_dim = 64
         self.decoder_output_dim = options['decoder_output_dim']
-        assert n_features == 32 and self.decoder_output_dim == 3, "HIP renderer is built for the released 32->64->4 decoder"
+        assert n_features == 32 and self.decoder_output_dim >= 3, "HIP renderer: 32 tri-plane features, at least the 3 colour outputs"
         self.net = nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim), nn.Softplus(),
                                  FullyConnectedLayer(self.hidden_dim, 1 + self.decoder_output_dim))
 
@@ -54,10 +60,10 @@ class Triplane(nn.Module):
         # 3 colour channels (nsr/script_util.py:1149,1357-1369): the variants below change what the ray marcher composites (32
         # feature channels into a super-resolution CNN, nsr/triplane.py:476-500,695-711; a background NeRF; the LRM decoder) and
         # are not built - they are refused here rather than silently rendering something else.
-        if sr_kwargs or bcg_synthesis_kwargs or lrm_decoder or create_triplane or decoder_output_dim != 3:
+        if sr_kwargs or bcg_synthesis_kwargs or lrm_decoder or create_triplane or decoder_output_dim < 3:
             raise NotImplementedError(
-                "Triplane: sr_kwargs / bcg_synthesis_kwargs / lrm_decoder / create_triplane / decoder_output_dim != 3 are outside the "
-                "sampling hot path (the released samplers use sr_kwargs={}, OSGDecoder with 3 colour channels); got "
+                "Triplane: sr_kwargs / bcg_synthesis_kwargs / lrm_decoder / create_triplane are outside the sampling hot path (every "
+                "released sampler passes --sr_training False -> sr_kwargs={}, no background model, the OSG decoder); got "
                 f"sr_kwargs={sr_kwargs!r}, bcg_synthesis_kwargs={bcg_synthesis_kwargs!r}, lrm_decoder={lrm_decoder}, "
                 f"create_triplane={create_triplane}, decoder_output_dim={decoder_output_dim}")
         self.superresolution = None                      # attribute of the reference class (nsr/triplane.py:500)
@@ -79,9 +85,9 @@ class Triplane(nn.Module):
         if self._dec is None or self._dec[0].device != dev or self._dec_epoch != _cache.EPOCH[0]:
             self._dec_epoch = _cache.EPOCH[0]
             _cache.watch_tree(self)
-            n = self.decoder.net
+            n = self.decoder.net                        # output rows 0 - 3 = sigma, r, g, b (a wider decoder's other rows feed SR only)
             self._dec = tuple(t.detach().to(dev, torch.float32).contiguous()
-                              for t in (n[0].weight, n[0].bias, n[2].weight, n[2].bias))
+                              for t in (n[0].weight, n[0].bias, n[2].weight[:4], n[2].bias[:4]))
         return self._dec
 
     @staticmethod

@@ -64,10 +64,10 @@ def render_call_kwargs(rk):
 def decoder_weights(decoder, device):
     """(w0, b0, w1, b1) of an OSGDecoder-shaped module (`net.0`, `net.2` FullyConnectedLayers: 32 -> 64 -> 1 + 3)."""
     n = decoder.net
-    w = tuple(t.detach().to(device, torch.float32).contiguous() for t in (n[0].weight, n[0].bias, n[2].weight, n[2].bias))
-    if tuple(w[0].shape) != (64, 32) or tuple(w[2].shape) != (4, 64):
-        raise NotImplementedError("the HIP renderer is built for the released 32 -> 64 -> 4 OSGDecoder")
-    return w
+    if tuple(n[0].weight.shape) != (64, 32) or n[2].weight.shape[1] != 64 or n[2].weight.shape[0] < 4:
+        raise NotImplementedError("the HIP renderer is built for the released 32 -> 64 -> (1 + C) OSGDecoder, C >= 3")
+    # rows 0 - 3 = sigma, r, g, b; further colour rows (decoder_output_dim 32) only feed the SR module no released sampler builds
+    return tuple(t.detach().to(device, torch.float32).contiguous() for t in (n[0].weight, n[0].bias, n[2].weight[:4], n[2].bias[:4]))
 
 
 class ImportanceRenderer(nn.Module):

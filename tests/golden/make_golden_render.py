@@ -146,8 +146,11 @@ def sec_render_presets():
     check, save = mg.check, mg.save
     print('== renderer presets + return_meta (reference Triplane.forward vs oracle.render)')
     from nsr.triplane import Triplane
-    cases = dict(PRESETS, objv64_meta=(orender.OBJAVERSE_OPTS, 16, 2, 1.7719))
+    cases = dict(PRESETS, objv64_meta=(orender.OBJAVERSE_OPTS, 16, 2, 1.7719), shapenet64_d32=(orender.SHAPENET_OPTS, 16, 2, 1.2))
     for tag, (opts, res, V, radius) in cases.items():
+        if tag == 'shapenet64_d32':
+            _shapenet_d32(tag, opts, res, V, radius, check, save)
+            continue
         rk = ref_preset_kwargs(opts)
         if 'auto' in str(opts['ray_start']):
             rk.update(PatchRaySampler=True, patch_rendering_resolution=45)       # the Objaverse presets carry it (:788)
@@ -198,6 +201,39 @@ def sec_render_presets():
              all_coords=r_ref['all_coords'].half(), feature_volume=r_ref['feature_volume'].half(),
              coarse_densities=ss['coarse_densities'].half(), fine_depths=det['fine_depths'].half(), cams=cams, jitter_seed=np.array(0),
              plane_scale=np.array(4.0), sigma_bias=np.array(4.0), res=np.array(res), radius=np.array(radius))
+
+
+def _shapenet_d32(tag, opts, res, V, radius, check, save):
+    """The ShapeNet launchers' renderer: --decoder_output_dim 32 (33-row decoder), --sr_training False -> no SR module; image_raw is the first 3
+    of the 32 composited feature channels (nsr/triplane.py:683)."""
+    from nsr.triplane import Triplane
+    from ln3diff_amd.synth import synth_state_dict
+    tp = Triplane(25, res, 3, rendering_kwargs=ref_preset_kwargs(opts), out_chans=96, triplane_size=224, decoder_in_chans=32, decoder_output_dim=32,
+                  sr_kwargs={}, bcg_synthesis_kwargs={}, lrm_decoder=False).eval()
+    assert tp.superresolution is None
+    sd = synth_state_dict({'net.0.weight': (64, 32), 'net.0.bias': (64,), 'net.2.weight': (33, 64), 'net.2.bias': (33,)}, 0)
+    sd['net.2.bias'] = sd['net.2.bias'].clone()
+    sd['net.2.bias'][0] += 4.0
+    tp.decoder.load_state_dict(sd, strict=True)
+    planes = synth_input('planes', (V, 96, 128, 128), 3, 4.0)
+    cams = orbit_cameras(8, radius=radius)[[1, 6][:V]]
+    M, S, NI = res * res, opts['depth_resolution'], opts['depth_resolution_importance']
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r_ref = tp(planes, cams)
+    torch.manual_seed(0)
+    jitter = torch.rand(V, M, S, 1)
+    u_fine = torch.rand(V * M, NI)
+    sd4 = dict(sd)
+    sd4['net.2.weight'], sd4['net.2.bias'] = sd['net.2.weight'][:4], sd['net.2.bias'][:4]
+    r = orender.triplane_render(planes, sd4, cams, res, jitter, u_fine, opts)
+    assert r_ref['feature_image'].shape[1] == 32
+    check(f'{tag} image_raw (= feature_image[:, :3])', r['image_raw'], r_ref['image_raw'], 1e-4)
+    check(f'{tag} image_depth', r['image_depth'], r_ref['image_depth'], 1e-4)
+    check(f'{tag} weights_samples', r['weights_samples'], r_ref['weights_samples'], 1e-4)
+    save(f'render_preset_{tag}', image_raw=r_ref['image_raw'], image_depth=r_ref['image_depth'], weights_samples=r_ref['weights_samples'],
+         image_mask=r_ref['image_mask'], cams=cams, jitter_seed=np.array(0), plane_scale=np.array(4.0), sigma_bias=np.array(4.0),
+         res=np.array(res), radius=np.array(radius))
 
 
 # ------------------------------------------------------------------ VAE decode

@@ -140,13 +140,17 @@ def test_bench_refuses_wrong_gpu_counts(argv, env, msg):
 
 
 def test_renderer_variants_outside_the_hot_path_are_refused():
-    """Triplane(sr_kwargs=..., bcg_synthesis_kwargs=..., lrm_decoder=True, decoder_output_dim=32) change what the ray marcher
-    composites (nsr/triplane.py:476-500): not built, and not silently ignored either."""
+    """Triplane(sr_kwargs=..., bcg_synthesis_kwargs=..., lrm_decoder=True) change what the ray marcher composites
+    (nsr/triplane.py:476-500): not built, and not silently ignored either.  No released sampler builds them (every launcher passes
+    --sr_training False -> sr_kwargs = {}).  decoder_output_dim = 32 (the ShapeNet launchers) IS taken: without the SR module only its
+    first 3 colour rows reach image_raw, and the state dict keeps the reference's 33-row shape."""
     from ln3diff_amd.nsr.triplane import Triplane
     assert Triplane(img_resolution=16, sr_kwargs={}, bcg_synthesis_kwargs={}).superresolution is None
-    for kw in (dict(sr_kwargs={'channel_base': 32768}), dict(lrm_decoder=True), dict(decoder_output_dim=32), dict(bcg_synthesis_kwargs={'a': 1})):
+    for kw in (dict(sr_kwargs={'channel_base': 32768}), dict(lrm_decoder=True), dict(decoder_output_dim=2), dict(bcg_synthesis_kwargs={'a': 1})):
         with pytest.raises(NotImplementedError):
             Triplane(img_resolution=16, **kw)
+    tp = Triplane(img_resolution=16, decoder_output_dim=32)
+    assert tuple(tp.state_dict()['decoder.net.2.weight'].shape) == (33, 64) and tp.superresolution is None
 
 
 def test_encoded_images_are_read_through_pillow(tmp_path):

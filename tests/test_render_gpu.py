@@ -161,6 +161,33 @@ def test_render_presets_vs_reference_golden(hip_lib, tag):
         assert e < 2e-3, (key, e)
 
 
+def test_shapenet_renderer_with_the_32_channel_decoder_vs_reference_golden(hip_lib):
+    """The ShapeNet launchers' renderer: numeric ray limits, no bbox filter, --decoder_output_dim 32 with --sr_training False (no SR
+    module): image_raw = the first 3 of the reference's 32 composited channels (nsr/triplane.py:683)."""
+    from oracle import render as orender
+    from ln3diff_amd.nsr.triplane import Triplane
+    from ln3diff_amd.synth import synth_input, synth_state_dict
+    g = golden('render_preset_shapenet64_d32')
+    res = int(g['res'])
+    tp = Triplane(img_resolution=res, rendering_kwargs=dict(orender.SHAPENET_OPTS), decoder_output_dim=32)
+    sd = synth_state_dict({'net.0.weight': (64, 32), 'net.0.bias': (64,), 'net.2.weight': (33, 64), 'net.2.bias': (33,)}, 0)
+    sd['net.2.bias'] = sd['net.2.bias'].clone()
+    sd['net.2.bias'][0] += float(g['sigma_bias'])
+    tp.decoder.load_state_dict(sd, strict=True)
+    tp = tp.cuda()
+    cams = torch.from_numpy(g['cams'])
+    V, M = cams.shape[0], res * res
+    planes = synth_input('planes', (V, 96, 128, 128), 3, float(g['plane_scale']))
+    gen = torch.Generator().manual_seed(int(g['jitter_seed']))
+    jitter = torch.rand(V, M, 64, 1, generator=gen).reshape(V, M, 64)
+    u_fine = torch.rand(V * M, 64, generator=gen)
+    out = tp(planes.cuda(), cams.cuda(), jitter=jitter, u_fine=u_fine)
+    for key in ('image_raw', 'image_depth', 'weights_samples', 'image_mask'):
+        e = rel_l2(out[key].cpu(), g[key])
+        print('shapenet d32', key, e)
+        assert e < 2e-3, (key, e)
+
+
 @pytest.mark.parametrize("tag", ['objv64_meta', 'shapenet64', 'objv128'])
 def test_importance_renderer_seam_outputs_vs_reference_golden(hip_lib, tag):
     """ImportanceRenderer.forward(planes, decoder, ray_origins, ray_directions, rendering_options, return_meta=True) - the reference's
