@@ -219,10 +219,10 @@ class EulerEDMSampler:
             g['mod_step']['mod'].copy_(mod_all['mod'][i * g['mrows']:(i + 1) * g['mrows']])
             g['graph'].replay()
             eps2 = g['eps']
-        elif mod_all is not None:
-            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i))
+        elif mod_all is not None:      # cfg_twins: [uc ; c] are the same latents, timestep and c_in twice (VanillaCFG.prepare_inputs)
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i), cfg_twins=_TWINS)
         else:
-            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'])
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], cfg_twins=_TWINS)
         ops.edm_euler_step(st['x'], eps2, sig, float(st['sigmas'][i + 1]), float(self.guider.scale))
 
     def _capture(self, network, st, mod_all, dev):
@@ -238,11 +238,11 @@ class EulerEDMSampler:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces, kernel attributes
-            network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0))
+            network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=_TWINS)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0))
+            eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=_TWINS)
         st['graph'] = {'graph': graph, 'eps': eps_g, 'mod_step': mod_step, 'mrows': mrows}
 
     def _fast(self, den, network, x, cond, uc, num_steps, trace):
@@ -299,6 +299,7 @@ class EulerEDMSampler:
         return out
 
 
+_TWINS = not os.environ.get('LN3D_NO_TWINS')      # measurement switch of the r5 A/B (block-0 dedup of the CFG halves)
 _LANE_STREAMS = {}
 
 

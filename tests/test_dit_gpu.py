@@ -158,3 +158,41 @@ def test_schedule_modulation_cache_forms(hip_lib):
         assert rel_l2(got, want) < 1e-5, step
     m.MODCACHE_MAX_BYTES = 1024
     assert m.prepare_timesteps(uniform) is None          # the samplers then run the modulation GEMMs per step
+
+
+@pytest.mark.parametrize("folded", [True, False])
+def test_cfg_twins_block0_dedup_is_exact_algebra(hip_lib, monkeypatch, folded):
+    """r5: with `cfg_twins=True` (the samplers' statement that the two halves of the CFG batch enter with the same latent, timestep
+    and input scale) block 0's norm / QKV / self-attention run on one half.  Same network output as the plain forward on the same
+    inputs up to summation order and the tile chosen for the halved row count; with and without the zero-context fold."""
+    from ln3diff_amd.dit.dit_trilatent import DiT_TriLatent
+    from ln3diff_amd.dit.dit_models_xformers import TextCondDiTBlock
+    from ln3diff_amd.synth import synth_input
+    if not folded:
+        monkeypatch.setenv('LN3D_NO_UC_FOLD', '1')
+    m = DiT_TriLatent(input_size=32, patch_size=2, in_channels=4, hidden_size=256, depth=3, num_heads=4, num_classes=0, learn_sigma=False,
+                      context_dim=768, roll_out=True, vit_blk=TextCondDiTBlock)
+    load_synth(m, 0)
+    m = m.cuda()
+    B = 2
+    x = synth_input('x', (B, 12, 32, 32), 2).cuda()                       # Bx = B latents, network batch 2B = [uc ; c]
+    c = synth_input('c', (B, 77, 768), 2).cuda()
+    cc = m.prepare_context(torch.cat([torch.zeros_like(c), c]))
+    assert cc['fold'] == (B if folded else 0)
+    sched = torch.tensor([900., 500.])[:, None].expand(2, 2 * B)
+    mc = m.prepare_timesteps(sched)
+    assert mc['rows'] == 1
+    sc = torch.full((2 * B,), 0.37, device='cuda')
+    for step in range(2):
+        t = sched[step].cuda()
+        want = m(x, t, context_cache=cc, in_scale=sc, mod_cache=(mc, step)).clone()
+        got = m(x, t, context_cache=cc, in_scale=sc, mod_cache=(mc, step), cfg_twins=True)
+        e = rel_l2(got, want)
+        print('cfg twins dedup, folded', folded, 'step', step, e)
+        assert e < 1e-3, e
+    # not applied when the modulation rows differ per sample (per-sample timesteps): the flag alone does not force it
+    ragged = torch.tensor([[900., 800., 700., 600.]])
+    mr = m.prepare_timesteps(ragged)
+    a = m(x, ragged[0].cuda(), context_cache=cc, mod_cache=(mr, 0)).clone()
+    b = m(x, ragged[0].cuda(), context_cache=cc, mod_cache=(mr, 0), cfg_twins=True)
+    assert torch.equal(a, b)
