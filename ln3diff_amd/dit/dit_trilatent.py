@@ -294,123 +294,6 @@ class DiT_TriLatent(DiT):
         half = Bn // 2
         dedup0 = bool(kwargs.get('cfg_twins', False)) and 2 * Bx == Bn and ld == 0 and fold in (0, half)
         for i, q in enumerate(P['blocks']):
-            ops.gemm(cp, q['ckv_w'], None, ops.EPI_HEADS, k_all[i], vt_all[i], M=Bn * Lc, tokens=Lc, tok_pad=lpad,
-                     heads=H, head_dim=dh, transpose_mask=0b10)
-        # K copy whose 64 head dims are stored in the 16-group order [0-3, 8-11, 4-7, 12-15]: the order in which the query
-        # projection's accumulators hand q to the MFMA when cross-attention runs inside that GEMM (LN3D_EPI_CROSS_ATTN)
-        kp_all = k_all[..., ops.vt_key_order(dh, dev)].contiguous()
-        cc = {'k': k_all, 'kp': kp_all, 'vt': vt_all, 'Lc': Lc, 'lpad': lpad, 'Bn': Bn, 'fold': 0}
-        # Samples whose context rows are all IDENTICAL - the zero embeddings of the unconditional CFG branch (force_uc_zero_embeddings,
-        # sgm_DiffusionEngine.py:448-452; the caption MLP turns them into 77 copies of one row): every key of such a sample is the same
-        # vector, softmax over identical scores is uniform whatever the query, and the cross-attention sub-block is the constant
-        # to_out(v) + b per (layer, sample).  For a leading run of such samples ([uc, c] order) the constants are computed here, once
-        # per prompt, with the same kernels (bf16 V row -> to_out GEMM, fp32 accumulate), and forward() adds them in the epilogue of
-        # the preceding GEMM instead of running to_q / attention / to_out on those rows (LN3D_NO_UC_FOLD=1: off).
-        if not os.environ.get('LN3D_NO_UC_FOLD') and Lc > 1 and Bn > 1:
-            same = (context == context[:, :1]).flatten(1).all(1)                 # [Bn]: one host read per prompt
-            fold = 0
-            for v in same.tolist():
-                if not v:
-                    break
-                fold += 1
-            if 0 < fold < Bn:
-                const = torch.zeros(self.depth, Bn, D, dtype=torch.float32, device=dev)      # rows >= fold stay 0
-                for i, q in enumerate(P['blocks']):
-                    v_row = vt_all[i, :fold, :, :, 0].reshape(fold, H * dh).contiguous()     # V^T[b, h, d, key 0] = the attention output
-                    ops.gemm(v_row, q['co_w'], q['co_b'], ops.EPI_F32, const[i, :fold])
-                cc['fold'], cc['const'] = fold, const
-        return cc
-
-    # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def _modulation(self, timesteps, mod, tag):
-        """t -> sincos(256) -> MLP -> SiLU -> adaLN Linear of every block + final layer, all rows of `timesteps` at once."""
-        P, ws, D = self._packed, self._ws, self.embed_dim
-        R = timesteps.shape[0]
-        t32 = timesteps.to(device=mod.device, dtype=torch.float32).contiguous()
-        tf = ws.get(tag + 'tfreq', (R, 256), torch.bfloat16)
-        ops.timestep_embedding(t32, tf, R, 256)
-        th = ws.get(tag + 'th', (R, D), torch.bfloat16)
-        ops.gemm(tf, P['t_w0'], P['t_b0'], ops.EPI_SILU, th)
-        temb = ws.get(tag + 'temb', (R, D), torch.float32)
-        tsilu = ws.get(tag + 'tsilu', (R, D), torch.bfloat16)
-        ops.gemm(th, P['t_w2'], P['t_b2'], ops.EPI_F32_SILU, temb, tsilu)
-        ops.gemm(tsilu, P['ada_w'], P['ada_b'], ops.EPI_F32, mod)
-
-    MODCACHE_MAX_BYTES = 4 << 30
-
-    def prepare_timesteps(self, t_table):
-        """t_table [n_steps, Bn] (the sampler's whole schedule): the timestep-only part of the network (embedder MLP and the
-        [24*6+2]*D-wide adaLN projection, 306 MB of weights at DiT-L/2) is evaluated for all steps in ONE pass instead of
-        re-streaming those weights every step.  Returns the cache for forward(..., mod_cache=(cache, step)): {'mod': [n * rows,
-        nmod] f32, 'rows': rows}.  When every sample of a step has the same timestep (all samplers of this path) ONE row per step is
-        kept (rows = 1: 150 MB at 250 steps instead of 2.4 GB at network batch 16) and the kernels read it with a sample stride of 0.
-        A schedule whose cache would exceed MODCACHE_MAX_BYTES returns None: the caller runs the modulation GEMMs per step."""
-        dev = next(self.parameters()).device
-        self._ensure_packed(dev)
-        n, Bn = t_table.shape
-        nmod = self.depth * 6 * self.embed_dim + 2 * self.embed_dim
-        rows = 1 if bool((t_table == t_table[:, :1]).all()) else Bn
-        if n * rows * nmod * 4 > self.MODCACHE_MAX_BYTES:
-            return None
-        mod_all = self._ws.get('mod_all', (n * rows, nmod), torch.float32)
-        self._modulation(t_table[:, :rows].reshape(-1).to(dev), mod_all, 'ma')
-        return {'mod': mod_all, 'rows': rows}
-
-    def forward(self, x, timesteps=None, context=None, y=None, get_attr='', context_cache=None, in_scale=None,
-                mod_cache=None, **kwargs):
-        if get_attr != '':
-            return getattr(self, get_attr)
-        assert context is not None or context_cache is not None
-        if not x.is_cuda:
-            raise RuntimeError("ln3diff_amd.DiT_TriLatent runs on the HIP device only (no CPU fallback)")
-        dev = x.device
-        self._ensure_packed(dev)
-        P, ws = self._packed, self._ws
-        D, H, depth = self.embed_dim, self.num_heads, self.depth
-        Bn = timesteps.shape[0]
-        Bx = x.shape[0]
-        S, p, C = self.input_size, self.patch_size, self.in_channels
-        L = (S // p) ** 2
-        N = 3 * L
-        M = Bn * N
-        cc = context_cache if context_cache is not None else self.prepare_context(context)
-        assert cc['Bn'] == Bn
-
-        # -- timestep embedding and all adaLN modulations (or the rows prepared for the whole schedule)
-        nmod = depth * 6 * D + 2 * D
-        ld = nmod                                              # stride between the samples' modulation rows
-        if mod_cache is not None:
-            mc, step = mod_cache
-            rows = mc['rows']
-            assert rows in (1, Bn) and mc['mod'].shape[1] == nmod
-            mod = mc['mod'][step * rows:(step + 1) * rows]
-            ld = nmod if rows == Bn else 0                     # one shared row per step: every sample reads row 0
-        else:
-            mod = ws.get('mod', (Bn, nmod), torch.float32)
-            self._modulation(timesteps, mod, 'm')
-
-        # -- tokens
-        xt = ws.get('x', (M, D), torch.float32)
-        ops.patch_embed(x.contiguous().float(), in_scale, P['pe_w'], P['pe_b'], P['pos'], xt, Bx, Bn, C, S, p, D)
-        hb = ws.get('h', (M, D), torch.bfloat16)
-        xb = ws.get('xb', (M, D), torch.bfloat16)
-        qc = ws.get('qc', (Bn, H, N, 64), torch.bfloat16)
-        oc = ws.get('oc', (M, H * 64), torch.bfloat16)
-        f1 = ws.get('f1', (M, P['blocks'][0]['fc1_w'].shape[0]), torch.bfloat16)
-
-        probe = getattr(self, '_fc1_probe', None)
-        fused_cross = N % 192 == 0 and (H * 64) % 256 == 0 and cc['Lc'] <= 96 and 'kp' in cc
-        fold = cc.get('fold', 0)
-        r0 = fold * N                                          # first token row that still runs the cross-attention GEMMs
-        # r5: under classifier-free guidance the two halves of the network batch ([uc ; c], the same latents and timestep twice) are
-        # IDENTICAL until the first cross-attention separates them, so block 0's norm, QKV projection and self-attention run on one half
-        # and its output projection is applied to both halves' residual rows (exact algebra, like the fold; LN3D_NO_UC_FOLD disables both).
-        # Conditions: the leading half is the folded one and every sample shares its modulation row (mod_ld == 0).
-        # `cfg_twins=True` is the caller's statement that sample b and sample b + Bn / 2 enter with the same latent, timestep and input
-        # scale (the samplers fill t and c_in with one constant per step; checking it here would be a device read per step).
-        dedup0 = bool(kwargs.get('cfg_twins', False)) and fold > 0 and 2 * fold == Bn and 2 * Bx == Bn and ld == 0
-        for i, q in enumerate(P['blocks']):
             o6 = i * 6 * D
             sh_a, sc_a, g_a = mod[:, o6:], mod[:, o6 + D:], mod[:, o6 + 2 * D:]
             sh_m, sc_m, g_m = mod[:, o6 + 3 * D:], mod[:, o6 + 4 * D:], mod[:, o6 + 5 * D:]
@@ -419,8 +302,8 @@ class DiT_TriLatent(DiT):
                 ops.norm_modulate(xt[:Mh], hb[:Mh], Mh, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=ld)
                 ao = self_attention_hip(ws, 'sa0_', hb[:Mh], half, N, D, H, q['qkv_w'], q['qkv_b'])
                 # first half: with the fold these are the unconditional rows (+ their constant cross-attention, no bf16 copy needed)
-                ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt[:Mh], None if fold else xb[:Mh], gate=g_a, gate_rows=N, gate_ld=ld,
-                         res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
+                ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt[:Mh], None if fold else xb[:Mh], gate=g_a, gate_rows=N,
+                         gate_ld=ld, res_bias=cc['const'][i] if fold else None, res_bias_ld=D)
                 ops.gemm(ao, q['proj_w'], q['proj_b'], ops.EPI_GATE_RES, xt[Mh:], xb[Mh:], gate=g_a, gate_rows=N, gate_ld=ld)
             else:
                 ops.norm_modulate(xt, hb, M, D, kind=0, eps=1e-6, shift=sh_a, scale=sc_a, mod_rows=N, mod_ld=ld)
