@@ -220,9 +220,9 @@ class EulerEDMSampler:
             g['graph'].replay()
             eps2 = g['eps']
         elif mod_all is not None:      # cfg_twins: [uc ; c] are the same latents, timestep and c_in twice (VanillaCFG.prepare_inputs)
-            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i), cfg_twins=_TWINS)
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i), cfg_twins=True)
         else:
-            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], cfg_twins=_TWINS)
+            eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], cfg_twins=True)
         ops.edm_euler_step(st['x'], eps2, sig, float(st['sigmas'][i + 1]), float(self.guider.scale))
 
     def _capture(self, network, st, mod_all, dev):
@@ -238,11 +238,11 @@ class EulerEDMSampler:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces, kernel attributes
-            network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=_TWINS)
+            network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=_TWINS)
+            eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=True)
         st['graph'] = {'graph': graph, 'eps': eps_g, 'mod_step': mod_step, 'mrows': mrows}
 
     def _fast(self, den, network, x, cond, uc, num_steps, trace):
@@ -299,7 +299,6 @@ class EulerEDMSampler:
         return out
 
 
-_TWINS = not os.environ.get('LN3D_NO_TWINS')      # measurement switch of the r5 A/B (block-0 dedup of the CFG halves)
 _LANE_STREAMS = {}
 
 

@@ -45,7 +45,7 @@ int main() {
   const int Dh = 64;
   const Case cases[] = {{16, 16, 768, 768, 0}, {16, 16, 768, 768, 1}, {16, 16, 1024, 1024, 0}, {32, 16, 512, 512, 1}, {32, 16, 512, 512, 0},
                         {2, 16, 768, 768, 1}, {1, 4, 700, 1000, 1}, {2, 3, 300, 832, 1}, {1, 2, 257, 257, 1}};
-  const struct { const char* name; } variants[] = {{"shipped kernel"}};     // r5: one kernel per shape class, no switches left
+  const struct { const char* name; int k1w; } variants[] = {{"shipped kernel", 0}, {"kres1w (r5)", 1}};
   const int ncases = getenv("ATTN_BENCH_CASES") ? atoi(getenv("ATTN_BENCH_CASES")) : 100;
   int ci = 0;
   for (const Case& c : cases) {
@@ -84,6 +84,7 @@ int main() {
     int vi = 0;
     for (const auto& var : variants) {
       if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
+      g_attn_kres1w = var.k1w;
       hipMemset(o, 0xff, no * 2);
       const int rc = ln3d_attention_bf16(&a, nullptr);
       hipError_t e = hipDeviceSynchronize();
