@@ -1,11 +1,13 @@
 // Stand-alone self-checking benchmark of ln3d_attention_bf16 (GPU box; build in the container, the binary ships with gpurun):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/attn_bench.hip -o build/attn_bench && build/attn_bench
-// For every case the kernel variants (the measurement switches of csrc/attention.hip, set directly in g_attn_cfg) are timed with
+// For every case the shipped kernel and - on the shapes it takes - the r5 experiment tools/attn_kres1w.hip (build with
+// -DLN3D_K1W_ABL=bits / -DLN3D_K1W_OPT=bits for its ablation / option builds) are timed with
 // HIP events on random data and their output is compared, element by element, with a naive fp32 kernel on the SAME bf16
 // operands.  Per head one key row is spiked against one query row: x3 (a score ~2^26 above the rest: the deferred-rebase branch
 // of the r1 / r2 kernels) or, in every third head, x40 (~2^346: overflows the fixed reference of attn_kres_kernel, so its
 // exact recomputation path runs); heads with bh % 5 == 1 carry the spike in the FIRST tile instead (everything else underflows).
 #include "../ln3diff_amd/csrc/attention.hip"
+#include "attn_kres1w.hip"   // r5 experiment: one wave per SIMD, AGPR-pinned accumulators (not in the library)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -84,16 +86,25 @@ int main() {
     int vi = 0;
     for (const auto& var : variants) {
       if (getenv("ATTN_BENCH_VAR") && atoi(getenv("ATTN_BENCH_VAR")) != vi++) continue;
-      g_attn_kres1w = var.k1w;
+      const bool k1w_shape = c.Nk >= 512 && c.Nk <= 768 && (c.Nk & 255) == 0 && (c.Nq & 255) == 0 && Nqp == c.Nq && Nkp == c.Nk && BH >= 256;
+      if (var.k1w && !k1w_shape) continue;
+      auto run = [&]() -> int {
+        if (!var.k1w) return ln3d_attention_bf16(&a, nullptr);
+        AttnP p;
+        p.Q = (const bf16_t*)a.Q; p.K = (const bf16_t*)a.K; p.Vt = (const bf16_t*)a.Vt; p.O = (bf16_t*)a.O;
+        p.B = a.B; p.H = a.H; p.Nq = a.Nq; p.Nq_pad = a.Nq_pad; p.Nk = a.Nk; p.Nk_pad = a.Nk_pad; p.ldo = a.ldo;
+        p.scale_log2 = a.scale * 1.4426950408889634f; p.causal = 0; p.nsplit = 1;
+        return launch_attn_kres1w(p, nullptr);
+      };
       hipMemset(o, 0xff, no * 2);
-      const int rc = ln3d_attention_bf16(&a, nullptr);
+      const int rc = run();
       hipError_t e = hipDeviceSynchronize();
       if (rc != 0 || e != hipSuccess) { printf("  %-18s FAILED rc %d hip %d\n", var.name, rc, (int)e); return 1; }
       std::vector<uint16_t> ho(no), ho2(no);
       hipMemcpy(ho.data(), o, no * 2, hipMemcpyDeviceToHost);
       size_t nd = 0;                                      // determinism: repeated launches must agree bit for bit
       for (int rep = 0; rep < 4; ++rep) {
-        ln3d_attention_bf16(&a, nullptr); hipDeviceSynchronize();
+        run(); hipDeviceSynchronize();
         hipMemcpy(ho2.data(), o, no * 2, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < no; ++i) nd += ho[i] != ho2[i];
       }
@@ -106,11 +117,11 @@ int main() {
         if (!(std::fabs(dlt) <= mxe)) mxe = std::fabs(dlt);
       }
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-      for (int i = 0; i < 5; ++i) ln3d_attention_bf16(&a, nullptr);
+      for (int i = 0; i < 5; ++i) run();
       float best = 1e30f, sum = 0.f;
       for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) ln3d_attention_bf16(&a, nullptr);
+        for (int i = 0; i < 20; ++i) run();
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = fminf(best, ms / 20); sum += ms / 20;
