@@ -1040,7 +1040,8 @@ static int launch(const GemmP& p, hipStream_t s) {
 }
 
 // cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (8 waves), 12 = 384f x 192t (12 waves,
-// 3 per SIMD), 14 = 128f x 192t (4 waves).  r2's 384x192 / 8-wave and 256x256 / 4-wave variants (11, 13) were measured slower and are gone.
+// 3 per SIMD), 14 = 128f x 192t (4 waves), 13 = 256f x 256t with 4 waves (r5: long-K GEMMs only, see pick_cfg).  r2's 384x192 / 8-wave variant (11) was
+// measured slower and is gone.
 template <int EPI>
 static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
   if constexpr (EPI == LN3D_EPI_CROSS_ATTN) return cfg == 14 ? launch_ring64<EPI, 4, 2, 2, 3>(p, s) : launch_ring64<EPI, 8, 2, 2, 3>(p, s);
@@ -1051,6 +1052,10 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
     case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
     case 12: return launch_ring64<EPI, 12, 2, 2, 3>(p, s);
     case 14: return launch_ring64<EPI, 4, 2, 2, 3>(p, s);      // 128f x 192t, 4 waves, 80 KB: two workgroups per CU (the half-batch GEMMs)
+    case 13:   // 256f x 256t with 4 waves: ONE wave per SIMD, 128 x 128 per wave, the 16 accumulator tiles in AGPRs (hipcc allocates them
+               // there by itself: only MFMAs touch them inside the K loop).  Instantiated for the epilogues that have long-K users.
+      if constexpr (EPI == LN3D_EPI_GATE_RES || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_F32) return launch_ring64<EPI, 4, 2, 4, 4>(p, s);
+      else return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
     default: return launch<EPI>(p, s);
   }
 }
@@ -1071,7 +1076,7 @@ static int forced_cfg() {
   return g_gemm_forced;
 }
 extern "C" void ln3d_gemm_reload_env(void) { g_gemm_forced = -2; }
-static int pick_cfg(int M, int N, bool head_aligned = false, hipStream_t s = nullptr) {
+static int pick_cfg(int M, int N, bool head_aligned = false, hipStream_t s = nullptr, int K = 0, int epi = -1) {
   if (forced_cfg() >= 0) return forced_cfg();
   if (!(M >= 1536 && N >= 128)) return 0;
   static const struct { int cfg, bf, bt; float speed; } C[4] = {{7, 256, 256, 1.0f}, {12, 384, 192, 1.0f}, {9, 256, 192, 0.95f},
@@ -1093,6 +1098,13 @@ static int pick_cfg(int M, int N, bool head_aligned = false, hipStream_t s = nul
     const int64_t t14 = (int64_t)((N + 127) / 128) * ((M + 191) / 192);
     if (t14 > best_tiles) best = 14;
   }
+  // r5: long K loops over several rounds of 256x256 tiles (the I23D family's fc2: 49152 x 1024 x 4096, 3 rounds) run faster with ONE
+  // wave per SIMD holding 128 x 128 (a third fewer LDS fragment bytes per flop): 372 - 379 us against 412, 500 against 538 at M = 65536,
+  // bit-identical output.  With 16 K stages (K = 1024) the exposed prologue / epilogue of a lone wave costs more than the loop gains
+  // (fc1 111 vs 98 us), and below two rounds the tile count decides (T23D fc2 takes 256x192) - profiles/r5_gemm_x13.log, r5_gemm_x15.log.
+  // In situ (same-box A/B of the configs[2] line, temporary switch removed): 11.60 -> 11.70 samples/s, golden check unchanged.
+  if (best == 7 && K >= 2048 && best_tiles >= 2 * (int64_t)cus && (epi == LN3D_EPI_GATE_RES || epi == LN3D_EPI_BF16 || epi == LN3D_EPI_F32))
+    best = 13;
   return best;
 }
 
@@ -1132,7 +1144,7 @@ extern "C" int ln3d_gemm_bf16(const ln3d_gemm_args* a, void* stream) {
   const bool head_staged = a->epilogue == LN3D_EPI_HEADS && a->head_dim > 0 && (a->head_dim & 7) == 0 && a->heads > 0 &&
                            ((a->heads * a->head_dim) & 63) == 0 && a->tokens > 0 && (a->tokens & 31) == 0 && (a->M % a->tokens) == 0 &&
                            (a->N % 64) == 0;
-  const int cfg = pick_cfg(a->M, a->N, head_staged, s);
+  const int cfg = pick_cfg(a->M, a->N, head_staged, s, a->K, a->epilogue);
   switch (a->epilogue) {
     case LN3D_EPI_F32: return run_cfg<LN3D_EPI_F32>(p, s, cfg);
     case LN3D_EPI_BF16: return run_cfg<LN3D_EPI_BF16>(p, s, cfg);

@@ -11,7 +11,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x12", "x14"])
+@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x12", "x13", "x14"])
 def ops(hip_lib, request):
     """Every kernel test runs with the GEMM tile selection left to the library and forced to each tile config."""
     import os

@@ -75,6 +75,22 @@ int main(int argc, char** argv) {
       {"fc2 GATE_RES x14", 12288, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x14"},
       {"fc2 plain x14", 12288, 1024, 4096, LN3D_EPI_BF16, 768, "x14"},
       {"square 8192 plain x14", 8192, 8192, 8192, LN3D_EPI_BF16, 8192, "x14"},
+      {"fc1 GELU x13 (256x256, 4 waves)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x13"},
+      {"fc1 plain x13", 12288, 4096, 1024, LN3D_EPI_BF16, 768, "x13"},
+      {"qkv plain x13", 12288, 3072, 1024, LN3D_EPI_BF16, 768, "x13"},
+      {"proj GATE_RES x13", 12288, 1024, 1024, LN3D_EPI_GATE_RES, 768, "x13"},
+      {"proj plain x13", 12288, 1024, 1024, LN3D_EPI_BF16, 768, "x13"},
+      {"fc2 GATE_RES x13", 12288, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x13"},
+      {"fc2 plain x13", 12288, 1024, 4096, LN3D_EPI_BF16, 768, "x13"},
+      {"square 8192 plain x13", 8192, 8192, 8192, LN3D_EPI_BF16, 8192, "x13"},
+      {"i23d fc1 GELU M65536 x13", 65536, 4096, 1024, LN3D_EPI_GELU_ERF, 1024, "x13"},
+      {"i23d fc2 GATE_RES M65536 x13", 65536, 1024, 4096, LN3D_EPI_GATE_RES, 1024, "x13"},
+      {"fc2 GATE_RES x9", 12288, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x9"},
+      {"fc2 GATE_RES x7", 12288, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x7"},
+      {"i23d fc2 GATE_RES M65536 x7", 65536, 1024, 4096, LN3D_EPI_GATE_RES, 1024, "x7"},
+      {"i23d fc2 GATE_RES M65536 x9", 65536, 1024, 4096, LN3D_EPI_GATE_RES, 1024, "x9"},
+      {"i23d fc2 GATE_RES M49152 x13", 49152, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x13"},
+      {"i23d fc2 GATE_RES M49152", 49152, 1024, 4096, LN3D_EPI_GATE_RES, 768, nullptr},
       {"i23d qkv HEADS M49152", 49152, 3072, 1024, LN3D_EPI_HEADS, 768, nullptr},
       {"i23d fc1 GELU M65536", 65536, 4096, 1024, LN3D_EPI_GELU_ERF, 1024, nullptr},
       {"i23d fc2 GATE_RES M65536", 65536, 1024, 4096, LN3D_EPI_GATE_RES, 1024, nullptr},
