@@ -1,5 +1,6 @@
 #!/bin/bash
 # r5 GPU call 16: ring configuration 13 (256x256, one wave per SIMD) in the product: tile-sweep tests, the I23D goldens, same-box A/B of
+# (record of a GPU call: the temporary switch LN3D_NO_X13 existed only for this measurement and has been removed from the product since)
 # the configs[2] bench line with / without it
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

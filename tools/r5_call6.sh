@@ -1,5 +1,6 @@
 #!/bin/bash
 # r5 GPU call 6: bring-up of attn_kres1w_kernel (self-checking bench, both variants), the CFG-twins block-0 dedup test + same-box A/B
+# (record of a GPU call: the temporary switch LN3D_NO_TWINS existed only for this measurement and has been removed from the product since)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 timeout 300 build/attn_bench > gpurun_out/r5_attn1w_bench.log 2>&1; echo "attn_bench rc $?" >> gpurun_out/r5_attn1w_bench.log
