@@ -63,12 +63,123 @@ def build_models(dev, arch, dec_arch, seed=0, fill=True, golden_weights=False):
         if golden_weights:            # the (name, shape, seed) weights of tests/golden: lets the timed run be checked against a golden
             from ln3diff_amd.synth import load_synth_
             load_synth_(dit, seed)
+            load_synth_(dec, seed + 1)   # r6: the decoder too, so that the timed run's PICTURE can be checked (golden_check, full_chain_ditl2)
         else:
             fill_module_random_(dit, seed, dev)
-        fill_module_random_(dec, seed + 1, dev)
+            fill_module_random_(dec, seed + 1, dev)
         # keep the synthetic volume non-empty so compositing is exercised
         dec.triplane_decoder.decoder.net[2].bias.data[0] += 4.0
     return dit, dec
+
+
+class ClockSampler:
+    """Shader clock / socket power during a region, sampled by a thread through amdsmi's gpu_metrics (rank 0 only, ~10 Hz, read-only;
+    None values when the library is absent).  r6: the GEMMs run AT the 1 400 W cap with the clock pulled to 1.74 - 1.9 GHz
+    (profiles/r6_power.md), so every roofline fraction is printed with the clock it was measured at."""
+
+    def __init__(self, hz=20.0):
+        import threading
+        self.rows, self._stop, self.cap = [], threading.Event(), None
+        self._thr = threading.Thread(target=self._run, args=(hz,), daemon=True)
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self._h, self._smi = amdsmi.amdsmi_get_processor_handles()[0], amdsmi
+            try:
+                cap = amdsmi.amdsmi_get_power_cap_info(self._h).get('power_cap')
+                self.cap = cap / 1e6 if isinstance(cap, (int, float)) and cap > 100000 else cap
+            except Exception:                                   # noqa: BLE001
+                pass
+        except Exception:                                       # noqa: BLE001
+            self._smi = None
+
+    def _run(self, hz):
+        while not self._stop.is_set():
+            try:
+                m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
+                clk = [c for c in (m.get('current_gfxclks') or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+                pw = m.get('current_socket_power')
+                if clk and isinstance(pw, (int, float)):
+                    self.rows.append((time.time(), sum(clk) / len(clk), float(pw)))
+            except Exception:                                   # noqa: BLE001
+                pass
+            self._stop.wait(1.0 / hz)
+
+    def __enter__(self):
+        if self._smi is not None:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._smi is not None:
+            self._thr.join(timeout=2.0)
+
+    def summary(self, t0=None, t1=None, busy_w=600.0):
+        """Mean clock / power over [t0, t1]; *_busy = over the samples above busy_w watts (the denoise loop and the GEMM probes sit at
+        1.2 - 1.4 kW, idle at 0.25 - 0.3 kW)."""
+        r = [x for x in self.rows if (t0 is None or x[0] >= t0) and (t1 is None or x[0] <= t1)]
+        if not r:
+            return None
+        b = [x for x in r if x[2] >= busy_w] or r
+        return {"sclk_mhz": round(sum(x[1] for x in b) / len(b)), "power_w": round(sum(x[2] for x in b) / len(b)), "power_cap_w": self.cap,
+                "samples": len(b), "source": "amdsmi gpu_metrics current_gfxclks / current_socket_power, samples above %d W" % busy_w}
+
+
+def _with_clock(rec, clk, t0, t1, nominal_mhz=2400.0):
+    """sclk_mhz / power_w of the probe's own loop and frac_at_clock = achieved / (peak x sclk / 2400 MHz) beside the datasheet fraction."""
+    cs = clk.summary(t0, t1) if clk is not None else None
+    if cs and rec.get("frac") is not None and rec.get("bound") == "mfma":
+        rec["sclk_mhz"], rec["power_w"], rec["power_cap_w"] = cs["sclk_mhz"], cs["power_w"], cs["power_cap_w"]
+        rec["frac_at_clock"] = round(rec["achieved"] / (rec["peak"] * cs["sclk_mhz"] / nominal_mhz), 4)
+    elif cs:
+        rec["sclk_mhz"], rec["power_w"], rec["power_cap_w"] = cs["sclk_mhz"], cs["power_w"], cs["power_cap_w"]
+    return rec
+
+
+def mfma_probe(dev, seconds=1.0):
+    """What the matrix pipes of THIS box sustain on a pure-MFMA stream (ln3d_probe_mfma_bf16: no memory traffic, 2 x 256 workgroups x 8
+    waves), ~1 s of back-to-back launches.  Printed beside the datasheet peak; `frac` stays achieved / datasheet (the contract's peak and
+    comparable across rounds), `frac_of_sustained` = achieved / this."""
+    from ln3diff_amd import ops
+    wgs, iters = 512, 20000
+    out = torch.empty(wgs * 512, device=dev)
+    ops.probe_mfma(out, wgs, 200)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    n, fl = 0, 0.0
+    e0.record()
+    while time.time() - t0 < seconds:
+        for _ in range(4):
+            fl += ops.probe_mfma(out, wgs, iters)
+            n += 1
+        torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    return {"tflops": round(fl / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1), "launches": n, "t0": t0, "t1": time.time(),
+            "what": "ln3d_probe_mfma_bf16: 512 workgroups x 8 waves x 20000 x 8 v_mfma_f32_32x32x16_bf16, no memory traffic"}
+
+
+def _timed_loop(f, iters, min_seconds=0.6):
+    """Average launch time (ms) over back-to-back launches on the current stream, HIP events around the whole loop; batches of `iters`
+    until `min_seconds` have passed, so that the side-thread clock sampler sees the loop and the part reaches its sustained clock."""
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0, n = time.time(), 0
+    e0.record()
+    while True:
+        for _ in range(iters):
+            f()
+        n += iters
+        torch.cuda.synchronize()
+        if time.time() - t0 >= min_seconds:
+            break
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
 
 
 def roofline_probe(dev, n_net, D, iters=20, tokens=768):
@@ -80,15 +191,7 @@ def roofline_probe(dev, n_net, D, iters=20, tokens=768):
     w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
     b = torch.randn(N, device=dev) * 0.02
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    for _ in range(3):
-        ops.gemm(x, w, b, ops.EPI_GELU_ERF, y)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.gemm(x, w, b, ops.EPI_GELU_ERF, y)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _timed_loop(lambda: ops.gemm(x, w, b, ops.EPI_GELU_ERF, y), iters)
     flops = 2.0 * M * N * K
     peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
     ach = flops / (ms * 1e-3) / 1e12
@@ -109,21 +212,34 @@ def gate_res_probe(dev, n_net, D, iters=20, tokens=768):
     res = torch.randn(M, N, device=dev)
     gate = torch.randn(n_net, 6 * N, device=dev) * 0.1
     f = lambda: ops.gemm(x, w, b, ops.EPI_GATE_RES, res, None, gate=gate, gate_rows=tokens, gate_ld=6 * N)
-    for _ in range(3):
-        f()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _timed_loop(f, iters)
     flops = 2.0 * M * N * K
     ach = flops / (ms * 1e-3) / 1e12
     return {"kernel": "gemm_bf16_ring64_kernel<GATE_RES, 256x192> (DiT MLP fc2: gate * out + residual into the fp32 stream)", "shape": [M, N, K],
             "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "avg_us": round(ms * 1e3, 2),
             "traffic": pmc_traffic("gemm_fc2_gateres_%dx%dx%d" % (M, N, K))[0], "traffic_source": pmc_traffic("gemm_fc2_gateres_%dx%dx%d" % (M, N, K))[1],
             "algorithmic_bytes": "X %d MB + W %d MB read, %d MB residual read + written" % (M * K * 2 // 2 ** 20, N * K * 2 // 2 ** 20, M * N * 8 // 2 ** 20)}
+
+
+def out_proj_probe(dev, n_net, D, iters=40, tokens=768):
+    """The N = K = D members of the gate / residual family (attention out-proj; cross-attention to_out at half the rows): 25.8 GFLOP behind
+    a 100 MB fp32 residual read-modify-write - 203 flop per byte is UNDER the part's ridge (2500 / 8 = 312), so the bound is HBM / fabric
+    traffic (they were graded against the MFMA peak).  achieved = algorithmic bytes / time."""
+    from ln3diff_amd import ops
+    M, N, K = n_net * tokens, D, D
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) * 0.02
+    res = torch.randn(M, N, device=dev)
+    gate = torch.randn(n_net, 6 * N, device=dev) * 0.1
+    f = lambda: ops.gemm(x, w, b, ops.EPI_GATE_RES, res, None, gate=gate, gate_rows=tokens, gate_ld=6 * N)
+    ms = _timed_loop(f, iters)
+    byts = M * K * 2.0 + N * K * 2.0 + M * N * 8.0
+    return {"kernel": "gemm_bf16_ring64_kernel<GATE_RES> at N = K = %d (attention out-proj: gate * out + residual into the fp32 stream)" % D,
+            "shape": [M, N, K], "bound": "hbm", "achieved": round(byts / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(byts / (ms * 1e-3) / 1e9 / 8000.0, 4), "avg_us": round(ms * 1e3, 2), "traffic": None,
+            "algorithmic_bytes": "X %.1f MB + W %.1f MB read, %.1f MB residual read + written" % (M * K * 2 / 2 ** 20, N * K * 2 / 2 ** 20, M * N * 8 / 2 ** 20),
+            "mfma_frac_for_reference": round(2.0 * M * N * K / (ms * 1e-3) / 1e12 / 2500.0, 4)}
 
 
 def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
@@ -138,15 +254,7 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     if dt:
         q[..., dt:] = 0; k[..., dt:] = 0; vt[:, :, dt:, :] = 0
     o = torch.empty(n_net, Nq, H * (dt or Dh), device=dev, dtype=torch.bfloat16)
-    for _ in range(3):
-        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh, scale=Dh_true ** -0.5, dh_true=dt)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh, scale=Dh_true ** -0.5, dh_true=dt)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _timed_loop(lambda: ops.attention(q, k, vt, o, n_net, H, Nq, Nq, N, N, Dh, scale=Dh_true ** -0.5, dh_true=dt), iters)
     flops = 4.0 * Nq * N * H * Dh_true * n_net     # 4*Nq*Nkv*(H*Dh) per sample-layer (algorithmic: the true head size)
     ach = flops / (ms * 1e-3) / 1e12
     kres = N % 256 == 0 and 512 <= N <= 768 and Nq % 256 == 0 and Dh == 64 and n_net * H >= 256
@@ -338,6 +446,32 @@ def build_i23d(dev, arch, seed=0, fill=True, golden_weights=False):
     return dit
 
 
+def picture_check(latent0, rec_model, dec_arch):
+    """r6: the PICTURE of global sample 0 of the last timed step against the reference's (tests/golden/full_chain_ditl2.npz, made by
+    tests/golden/make_golden_full.py full_chain from the reference's own 250-step latent through the reference's AE + Triplane.forward):
+    sample 0's latent is decoded and view 0 of the 40-camera orbit re-rendered at 256^2 AFTER the timed region with the fixture's render
+    noise (stream seeded 0) and its triplane_scaling_divider 0.05 (at the released 0.96806 the random-init DiT's latent, std 18.7,
+    saturates the decoder and the fp32 reference and the fp32 oracle differ by 6 - 8 % themselves: nothing to pin there)."""
+    import numpy as np
+    from ln3diff_amd.nsr.triplane import draw_render_noise
+    from ln3diff_amd.pipeline import render_video_given_triplane
+    path = os.path.join(ROOT, 'tests', 'golden', 'full_chain_ditl2.npz')
+    if dec_arch != 'DiT2-L/2' or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    dev = latent0.device
+    cams = torch.from_numpy(g['cams'][0:1]).to(dev)
+    j, u = draw_render_noise(1, 256 * 256, 64, generator=torch.Generator().manual_seed(int(g['jitter_seed'])))
+    out = render_video_given_triplane(latent0[None].clone().float(), rec_model, cams, triplane_scaling_divider=float(g['divider']), jitter=j, u_fine=u,
+                                      resolution=256)
+    st = int(g['stride'])
+    rel = lambda a, b: float((a.double().cpu() - torch.from_numpy(b.astype(np.float64))).norm() / torch.from_numpy(b.astype(np.float64)).norm())
+    return {"rgb_rel_l2": round(rel(out['image_raw'][0, 0][:, ::st, ::st], g['image_raw_sub'][0]), 6),
+            "depth_rel_l2": round(rel(out['image_depth'][0, 0][:, ::st, ::st], g['image_depth_sub'][0]), 6),
+            "planes_rel_l2": round(rel(out['latent_after_vit'][0][:, ::8, ::8], g['planes_sub'][0]), 6),
+            "picture_fixture": "tests/golden/full_chain_ditl2.npz (view 0 of the orbit @ 256^2, divider 0.05, re-rendered after the timed region)"}
+
+
 def golden_check(latent0, i23d, arch, sample_steps):
     """Sample 0 of the timed run (global sample 0: the golden's inputs, weights and sampler settings) against the final latent of
     the reference's own B = 1 loop (tests/golden/full_edm_ditl2_250.npz / full_flow_pixartl2_euler50.npz, made by
@@ -375,8 +509,6 @@ def main():
     ap.add_argument("--ode-method", default="euler", choices=["euler", "heun", "dopri5"],
                     help="i23d workload: euler = configs[2] (50 fixed steps); dopri5 = the released sampler's default (torchdiffeq "
                          "semantics, atol 1e-6, rtol 1e-3: the number of network evaluations is decided by the solver and reported)")
-    ap.add_argument("--lanes", type=int, default=None,
-                    help="t23d: sub-batches of the denoise loop on their own HIP streams (EulerEDMSampler lanes; default: the sampler's)")
     ap.add_argument("--unfolded-steps", type=int, default=2,
                     help="extra steps after the timed region with the zero-context fold of the unconditional CFG half disabled "
                          "(prints value_unfolded; 0 = skip)")
@@ -447,8 +579,6 @@ def main():
         cond = {'crossattn': c_all[lo:hi].contiguous()}
         uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
         pipe = T23DPipeline(dit, dec, num_steps=args.sample_steps, cfg_scale=6.5)
-        if args.lanes is not None:
-            pipe.sampler.lanes = args.lanes
 
         eng = pipe
 
@@ -471,16 +601,21 @@ def main():
     # layer, every denoise step (an event pair costs ~1 us of stream time per 12 ms step)
     if rank == 0 and not args.no_probes:
         dit._fc1_probe = {'layer': dit.depth // 2, 'events': [], 'max': 4096}
+    clk = ClockSampler() if (rank == 0 and not args.no_probes) else None
+    if clk is not None:
+        clk.__enter__()
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    tw0 = time.time()
     for _ in range(args.steps):
         out = one_step()
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tw1 = time.time()
     dt = parallel.max_over_ranks(dt)
     ok = bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]['image_raw']).all())
     out_timed = out
@@ -537,11 +672,15 @@ def main():
                                       ("NOT folded (LN3D_NO_UC_FOLD=1)" if os.environ.get("LN3D_NO_UC_FOLD") else
                                        "cross-attention of the unconditional half folded; value_unfolded = the same step without the fold"))},
             "value_unfolded": value_unfolded,
-            "lanes": (getattr(getattr(eng, "sampler", None), "lanes", None) or int(os.environ.get("LN3D_LANES", "1") or 1)) if not i23d else 1,
             "finite": ok,
             "ranks_seen": seen, "collectives": parallel.collective_info(), "bcast_ms": round(bcast_ms, 2),
             "golden_check": golden_check(out[0][0], i23d, args.arch, args.sample_steps if (not i23d or args.ode_method == "euler") else -1),
         }
+        if not i23d and rec["golden_check"].get("fixture") == "tests/golden/full_edm_ditl2_250.npz":
+            pc = picture_check(out[0][0], eng.rec_model, args.dec_arch)
+            if pc:
+                rec["golden_check"].update(pc)
+                rec["golden_check"]["ok"] = bool(rec["golden_check"]["ok"] and pc["rgb_rel_l2"] < 1e-2)
         if i23d:
             rec["ode"] = {"method": args.ode_method}
             st = getattr(eng, "last_ode_stats", None)
@@ -551,18 +690,48 @@ def main():
         if not args.no_probes:
             D = dit.embed_dim
             ev = fc1_events
+            rec["clock_timed_region"] = clk.summary(tw0, tw1)        # the denoise loop's own clock / power (the whole step above 600 W)
+            tp0 = time.time()
             rec["roofline"] = roofline_probe(dev, 2 * B, D, tokens=768)
+            tp1 = time.time()
             if ev:
                 us = sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3
                 r = rec["roofline"]
-                r["isolated_loop_avg_us"] = r["avg_us"]          # 20 back-to-back launches of the same GEMM after the run
+                r["isolated_loop_avg_us"] = r["avg_us"]          # >= 0.6 s of back-to-back launches of the same GEMM after the run
+                ci = clk.summary(tp0, tp1)
+                if ci:
+                    r["isolated_loop_sclk_mhz"], r["isolated_loop_power_w"] = ci["sclk_mhz"], ci["power_w"]
                 r["avg_us"] = round(us, 2)                       # in situ: mean over the timed region's launches (HIP events)
                 r["launches_timed"] = len(ev)
                 r["achieved"] = round(r["algorithmic_flop_per_launch"] / (us * 1e-6) / 1e12, 1)
                 r["frac"] = round(r["achieved"] / r["peak"], 4)
+                cs = rec["clock_timed_region"]
+                if cs:          # in situ: the clock of the timed region itself
+                    r["sclk_mhz"], r["power_w"], r["power_cap_w"] = cs["sclk_mhz"], cs["power_w"], cs["power_cap_w"]
+                    r["frac_at_clock"] = round(r["achieved"] / (r["peak"] * cs["sclk_mhz"] / 2400.0), 4)
+            else:
+                _with_clock(rec["roofline"], clk, tp0, tp1)
+            tp0 = time.time()
             rec["roofline_attention"] = attention_probe(dev, 2 * B, dit.num_heads, 1024 if i23d else 768, D // dit.num_heads, Nq=768)
+            _with_clock(rec["roofline_attention"], clk, tp0, time.time())
             rec["roofline_raymarch"] = render_probe(dev, dec)
-            rec["roofline_gate_residual"] = gate_res_probe(dev, 2 * B, D, tokens=768)      # last: keeps the other probes comparable with r2 lines
+            tp0 = time.time()
+            rec["roofline_gate_residual"] = gate_res_probe(dev, 2 * B, D, tokens=768)
+            _with_clock(rec["roofline_gate_residual"], clk, tp0, time.time())
+            tp0 = time.time()
+            rec["roofline_out_proj"] = out_proj_probe(dev, 2 * B, D, tokens=768)
+            _with_clock(rec["roofline_out_proj"], clk, tp0, time.time())
+            mp = mfma_probe(dev)
+            cs = clk.summary(mp.pop("t0"), mp.pop("t1"))
+            if cs:
+                mp.update(sclk_mhz=cs["sclk_mhz"], power_w=cs["power_w"])
+            rec["mfma_sustained_probe"] = mp
+            for key in ("roofline", "roofline_attention", "roofline_gate_residual"):
+                r = rec[key]
+                r["peak_datasheet"] = r["peak"]
+                r["peak_sustained_probe"] = mp["tflops"]
+                r["frac_of_sustained"] = round(r["achieved"] / mp["tflops"], 4)
+            clk.__exit__()
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.arch, args.sample_steps, args.views, args.res, B, i23d=i23d)
         print(json.dumps(rec), flush=True)

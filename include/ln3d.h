@@ -29,15 +29,14 @@ int ln3d_abi_version(void);
  * is read ONCE per process, at the first launch that consults it.  A harness that changes it afterwards calls this to have it re-read. */
 void ln3d_reload_env(void);
 
-/* ---------------------------------------------------------------- streams that own part of the chip (ABI 9)
- * The reference runs its sampling loop on ONE CUDA stream (torch's current stream; nsr/lsgm/sgm_DiffusionEngine.py:386-407).
- * Here independent sub-batches of that loop ("lanes") may run on streams restricted to disjoint sets of compute units:
- * mask bit i = XCD (i % 8), CU (i / 8) of that XCD (hipExtStreamCreateWithCUMask); `words` 32-bit words.  The tile selection of
- * the kernels launched on such a stream counts the mask's compute units instead of the device's.  The stream lives for the
- * process (at most 32 of them). */
+/* Compute units of the current device (the tile selection of the GEMM / attention launchers counts them).  ABI 9 also had
+ * ln3d_stream_create_cu_mask / ln3d_stream_cu_count (streams restricted to a subset of the CUs, for an experiment that measured
+ * neutral: profiles/r5_lanes.md); removed in ABI 10. */
 int ln3d_device_cus(void);
-int ln3d_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
-int ln3d_stream_cu_count(void* stream);
+/* Diagnostic (ABI 10): a pure-MFMA stream (wgs workgroups x 8 waves x iters x 8 v_mfma_f32_32x32x16_bf16, no memory traffic) whose timing
+ * gives the matrix rate this box SUSTAINS under its power management - bench.py prints it beside the datasheet peak.  out: wgs * 512 floats.
+ * flop = wgs * 8 * iters * 8 * 2 * 32 * 32 * 16.  No reference counterpart (measurement only). */
+int ln3d_probe_mfma_bf16(float* out, int wgs, int iters, void* stream);
 
 /* ---------------------------------------------------------------- GEMM with fused epilogues
  * out[m, n] = epilogue( sum_k X[m,k] * W[n,k] + bias[n] ),  X:[M,K] bf16 (tokens), W:[N,K] bf16

@@ -15,7 +15,7 @@ SYMBOLS = [
     "ln3d_edm_euler_step", "ln3d_ddpm_step", "ln3d_flow_euler_step", "ln3d_axpby",
     "ln3d_planes_to_channel_last", "ln3d_planes_to_nchw", "ln3d_render_triplane",
     "ln3d_query_points", "ln3d_groupnorm_swish", "ln3d_im2col3x3", "ln3d_patch_embed_triplane", "ln3d_tile_rows", "ln3d_add_table_rows", "ln3d_cfg_combine_dup", "ln3d_ddim_step", "ln3d_mesh_count", "ln3d_mesh_emit", "ln3d_mcubes_count", "ln3d_mcubes_emit", "ln3d_lincomb", "ln3d_err_ratio_sq", "ln3d_embed_tokens", "ln3d_layernorm_f32", "ln3d_vit_patchify", "ln3d_vit_assemble", "ln3d_image_preprocess", "ln3d_plucker_rays",
-    "ln3d_device_cus", "ln3d_stream_create_cu_mask", "ln3d_stream_cu_count",
+    "ln3d_device_cus", "ln3d_probe_mfma_bf16",
     "ln3d_groupnorm_any", "ln3d_im2col3x3_strided", "ln3d_geglu", "ln3d_attention_small", "ln3d_nchw_to_cl_bf16", "ln3d_cl_to_nchw_f32",
     "ln3d_mix_prediction",
 ]
@@ -91,7 +91,7 @@ def check_symbols():
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise RuntimeError(f"libln3d_hip.so lacks symbols: {missing}")
-    assert L.ln3d_abi_version() == 9
+    assert L.ln3d_abi_version() == 10
     return True
 
 

@@ -730,7 +730,7 @@ extern "C" const char* ln3d_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int ln3d_abi_version(void) { return 9; }
+extern "C" int ln3d_abi_version(void) { return 10; }
 extern "C" void ln3d_gemm_reload_env(void);
 extern "C" void ln3d_attn_reload_env(void);
 extern "C" void ln3d_reload_env(void) { ln3d_gemm_reload_env(); ln3d_attn_reload_env(); }

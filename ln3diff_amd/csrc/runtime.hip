@@ -1,20 +1,9 @@
-// Stream facilities of the C ABI (include/ln3d.h): HIP streams restricted to a subset of the compute units, so that independent
-// sub-batches of the denoise loop ("lanes", ln3diff_amd/sgm/sampling.py) own disjoint halves of the chip and run fully
-// asynchronously - one lane's HBM-bound phases (norms, residual read-modify-write epilogues) fall under the other's MFMA main
-// loops instead of every CU of the device doing the same phase at the same time.
-//
-// CU mask bit i of hipExtStreamCreateWithCUMask addresses XCD (i % 8), CU (i / 8) of that XCD on this part (the driver deals
-// the bits round-robin over the 8 XCDs), so "every other CU of every XCD" keeps the GEMMs' XCD-aware tile walk (block b on XCD
-// b % 8) intact, which a split by XCD would not.
+// Device queries of the C ABI (include/ln3d.h).  r5's CU-masked stream registry (ln3d_stream_create_cu_mask, ABI 9) served an
+// experiment that measured neutral (profiles/r5_lanes.md) and is gone with ABI 10: every launch sizes its tiling for the whole device.
 #include "common.h"
 #include "../../include/ln3d.h"
 
-namespace {
-struct Masked { hipStream_t s; int cus; };
-constexpr int kMaxMasked = 32;
-Masked g_masked[kMaxMasked];
-std::atomic<int> g_nmasked{0};
-int device_cus() {
+static int device_cus() {
   static int n = 0;
   if (n == 0) {
     int dev = 0, v = 0;
@@ -24,33 +13,37 @@ int device_cus() {
   }
   return n;
 }
-}  // namespace
 
-// compute units a launch on `s` can occupy: the mask's population for streams made by ln3d_stream_create_cu_mask, else the device's
-int ln3d_stream_cus(hipStream_t s) {
-  const int n = g_nmasked.load(std::memory_order_acquire);
-  for (int i = 0; i < n; ++i)
-    if (g_masked[i].s == s) return g_masked[i].cus;
-  return device_cus();
-}
+// compute units a launch on `s` can occupy (kept as a function of the stream: the launchers' tile selection calls it)
+int ln3d_stream_cus(hipStream_t) { return device_cus(); }
 
 extern "C" int ln3d_device_cus(void) { return device_cus(); }
 
-extern "C" int ln3d_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out) {
-  if (!mask || words <= 0 || words > 32 || !stream_out) return LN3D_ERR_BAD_ARG;
-  int bits = 0;
-  for (int w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
-  const int cus = device_cus();
-  if (bits <= 0) return LN3D_ERR_BAD_ARG;
-  if (bits > cus) bits = cus;
-  const int slot = g_nmasked.load(std::memory_order_acquire);
-  if (slot >= kMaxMasked) return LN3D_ERR_UNSUPPORTED;
-  hipStream_t s = nullptr;
-  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); return LN3D_ERR_LAUNCH; }
-  g_masked[slot].s = s; g_masked[slot].cus = bits;
-  g_nmasked.store(slot + 1, std::memory_order_release);
-  *stream_out = (void*)s;
-  return LN3D_OK;
+// ------------------------------------------------------------------ diagnostic: what the matrix pipes sustain on THIS box (bench.py's roofline)
+// `iters` x 8 independent v_mfma_f32_32x32x16_bf16 per wave, no memory traffic: 8 waves per workgroup, `wgs` workgroups.  out: wgs * 512 floats.
+// The rate is the part's power-managed one for a pure-MFMA stream on fixed non-zero operands (profiles/r6_power.md), not the datasheet's.
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float* out, int iters) {
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(threadIdx.x * 0.002f - i); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-
-extern "C" int ln3d_stream_cu_count(void* stream) { return ln3d_stream_cus((hipStream_t)stream); }
+extern "C" int ln3d_probe_mfma_bf16(float* out, int wgs, int iters, void* stream) {
+  if (!out || wgs <= 0 || iters <= 0) return LN3D_ERR_BAD_ARG;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(wgs), dim3(512), 0, (hipStream_t)stream, out, iters);
+  return ln3d_check_launch();
+}

@@ -17,22 +17,36 @@ __global__ __launch_bounds__(256) void gn_any_kernel(const float* x, const float
   const int total = HW * cpg;
   const float* xb = x + (int64_t)n * HW * C + c0;
   const float* ar = add_row ? add_row + (int64_t)n * C + c0 : nullptr;
-  float s = 0.f, q = 0.f;
+  // two centred passes (r6): E[x^2] - mean^2 in fp32 loses the variance when |mean| >> std (h + emb offsets, late U-Net
+  // activations); the group is L2-resident, so the extra read costs little.  Fixed-order tree sums: bitwise reproducible.
+  __shared__ float sh[256];
+  auto block_sum = [&](float v) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+  };
+  float s = 0.f;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int px = e / cpg, cc = e - px * cpg;
     float v = xb[(int64_t)px * C + cc];
     if (ar) v += ar[cc];
-    s += v; q += v * v;
+    s += v;
   }
-  __shared__ float sh[2][256];
-  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-    __syncthreads();
+  const float mean = block_sum(s) / (float)total;
+  float q = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int px = e / cpg, cc = e - px * cpg;
+    float v = xb[(int64_t)px * C + cc];
+    if (ar) v += ar[cc];
+    q += (v - mean) * (v - mean);
   }
-  const float mean = sh[0][0] / (float)total;
-  const float var = fmaxf(sh[1][0] / (float)total - mean * mean, 0.f);
+  const float var = block_sum(q) / (float)total;
   const float rs = rsqrtf(var + eps);
   bf16_t* yb = y + (int64_t)n * HW * C + c0;
   for (int e = threadIdx.x; e < total; e += 256) {

@@ -208,15 +208,17 @@ def f32(t, device):
 
 
 class Workspace:
-    """Shape-keyed cache of device scratch tensors (allocated once; no allocation in the step loop).  One set per HIP stream:
-    sub-batches that run concurrently on their own streams (sgm.sampling.EulerEDMSampler lanes) must not share activations."""
+    """Shape-keyed cache of device scratch tensors (allocated once; no allocation in the step loop).  One set per network instance:
+    a network's forwards are ordered on whatever stream the caller runs them on (the HIP-graph capture warms up and captures on one
+    persistent side stream, ordered against the caller's by events); concurrent forwards of ONE instance from several streams are
+    not supported (r5 keyed the set by stream handle for an experiment that is gone; it leaked a set per capture stream)."""
 
     def __init__(self, device):
         self.device = device
         self._t = {}
 
     def get(self, name, shape, dtype, zero=False):
-        key = (name, tuple(shape), dtype, torch.cuda.current_stream(self.device).cuda_stream)
+        key = (name, tuple(shape), dtype)
         t = self._t.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)

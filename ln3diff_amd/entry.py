@@ -74,11 +74,13 @@ def create_argparser(objaverse=True):
         ode_method='dopri5', use_ddim=False, clip_denoised=False, image_size=128, num_views=40 if objaverse else 24, export_mesh=False,
         mesh_grid=192, mesh_thres=10.0, logdir='./logs/sample', resume_checkpoint='', ddpm_model_path='', rec_model_path='',
         cond_path='', pose_path='', seed=41 if objaverse else 0, context_dim=768, learn_sigma=False, denoise_in_channels=4,
-        diffusion_input_size=32, roll_out=True, prompt=None, cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
+        diffusion_input_size=32, roll_out=objaverse, prompt=None, cfg='objverse_tuneray_aug_resolution_64_64_auto' if objaverse else 'shapenet',
         mv_input=False, num_mv_views=4, mv_dino_arch='vitl', clip_checkpoint='', dino_checkpoint='', tokenizer_dir='', image_path='',
         overwrite_diff_inp_size='', create_controlnet=False,
-        # the U-Net denoiser of the ShapeNet / FFHQ launchers (guided_diffusion/script_util.py create_model, --create_dit False there)
-        create_dit=True, num_channels=320, num_res_blocks=2, channel_mult='', attention_resolutions='4,2,1', num_heads=8,
+        # the U-Net denoiser of the ShapeNet / FFHQ launchers (guided_diffusion/script_util.py create_model).  r6: the second
+        # script's defaults are the reference's model_and_diffusion_defaults (script_util.py:123,132: create_dit False, roll_out False) -
+        # those launchers pass neither flag, so run verbatim they select the U-Net with a 12-channel latent, as in the reference
+        create_dit=objaverse, num_channels=320, num_res_blocks=2, channel_mult='', attention_resolutions='4,2,1', num_heads=8,
         num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=True, use_spatial_transformer=True, transformer_depth=1,
         dropout=0.0, mixing_logit_init=-6.0)
     d.update(_IGNORED_DEFAULTS)

@@ -286,22 +286,11 @@ def device_cus():
     return int(L.lib().ln3d_device_cus())
 
 
-def masked_stream(bits, device):
-    """A HIP stream restricted to the compute units whose mask bits are set (include/ln3d.h: bit i = XCD i % 8, CU i // 8), as a
-    torch stream object.  The stream lives for the process."""
-    nw = (max(bits) // 32) + 1
-    words = [0] * nw
-    for b in bits:
-        words[b // 32] |= 1 << (b % 32)
-    arr = (C.c_uint32 * nw)(*words)
-    out = C.c_void_p()
-    with torch.cuda.device(device):
-        L.check(L.lib().ln3d_stream_create_cu_mask(arr, nw, C.byref(out)), "stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
-def stream_cu_count(stream=None):
-    return int(L.lib().ln3d_stream_cu_count(C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)))
+def probe_mfma(out, wgs, iters):
+    """Diagnostic pure-MFMA stream (include/ln3d.h ln3d_probe_mfma_bf16); returns the flop it executes."""
+    assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= wgs * 512
+    L.check(L.lib().ln3d_probe_mfma_bf16(_p(out), int(wgs), int(iters), _stream()), "probe_mfma")
+    return wgs * 8 * iters * 8 * 2.0 * 32 * 32 * 16
 
 
 # ---------------------------------------------------------------- U-Net pieces (csrc/unet_ops.hip)

@@ -114,40 +114,68 @@ class BoundDenoiser:
         return self.denoiser(self.network, input, sigma, c, **self.kw)
 
 
+_REF_LAMBDA_OPS = {'LOAD_DEREF', 'LOAD_ATTR', 'LOAD_METHOD', 'LOAD_FAST', 'BUILD_TUPLE', 'BUILD_MAP', 'DICT_MERGE', 'CALL_FUNCTION_EX',
+                   'CALL_FUNCTION', 'CALL_METHOD', 'CALL_FUNCTION_KW', 'RETURN_VALUE', 'RESUME', 'COPY_FREE_VARS', 'PUSH_NULL', 'PRECALL', 'CALL',
+                   'LOAD_CONST', 'KW_NAMES'}
+_CALL_OPS = {'CALL_FUNCTION_EX', 'CALL_FUNCTION', 'CALL_METHOD', 'CALL_FUNCTION_KW', 'CALL'}
+
+
+def _is_reference_lambda(fn):
+    """True when `fn`'s code is the engine's closure and nothing else (sgm_DiffusionEngine.py:401-403):
+    `lambda input, sigma, c: self.denoiser(self.model, input, sigma, c, **additional_model_inputs)` - three positional arguments, ONE call,
+    the attribute names `denoiser` and `model` only, every argument passed through untouched.  A closure that post-processes the
+    denoised output, wraps the network or adds inputs has other opcodes / names and is run as written (generic loop)."""
+    import dis
+    code = getattr(fn, '__code__', None)
+    if code is None or code.co_argcount != 3 or code.co_kwonlyargcount or (code.co_flags & 0x0C):      # no *args / **kwargs of its own
+        return False
+    if set(code.co_names) != {'denoiser', 'model'}:
+        return False
+    ins = list(dis.get_instructions(code))
+    if any(i.opname not in _REF_LAMBDA_OPS for i in ins) or sum(i.opname in _CALL_OPS for i in ins) != 1:
+        return False
+    fast = [i.argval for i in ins if i.opname == 'LOAD_FAST']
+    return fast == list(code.co_varnames[:3])                  # input, sigma, c: each once, in order
+
+
 def _find_pair(denoiser):
     """(DiscreteDenoiser, ln3diff_amd network) behind the sampler's `denoiser` argument, or (None, None).
-    Recognised: BoundDenoiser; a Python closure whose cells hold the pair directly or an engine object with `.denoiser` and
-    `.model` (the reference's own lambda, sgm_DiffusionEngine.py:401-403).  Anything else runs the generic loop."""
+    Recognised (nothing heuristic): `BoundDenoiser` without extra inputs; a callable that opts in with
+    `_ln3d_pair = (denoiser, network)`; a closure whose CODE is exactly the reference's lambda over an engine object with
+    `.denoiser` / `.model` and an empty `additional_model_inputs` (_is_reference_lambda).  Anything else runs the generic loop."""
     if isinstance(denoiser, BoundDenoiser):
         return (denoiser.denoiser, denoiser.network) if not denoiser.kw and hasattr(denoiser.network, 'prepare_context') else (None, None)
+    pair = getattr(denoiser, '_ln3d_pair', None)
+    if pair is not None:
+        den, net = pair
+        return (den, net) if isinstance(den, DiscreteDenoiser) and hasattr(net, 'prepare_context') else (None, None)
+    if not _is_reference_lambda(denoiser):
+        return None, None
     den = net = None
-    extra = False
     for cell in getattr(denoiser, '__closure__', None) or ():
         try:
             o = cell.cell_contents
         except ValueError:
-            continue
-        if isinstance(o, DiscreteDenoiser):
-            den = o
-        elif hasattr(o, 'prepare_context') and callable(o):
-            net = o
-        elif isinstance(getattr(o, 'denoiser', None), DiscreteDenoiser) and hasattr(getattr(o, 'model', None), 'prepare_context'):
+            return None, None
+        if isinstance(getattr(o, 'denoiser', None), DiscreteDenoiser) and hasattr(getattr(o, 'model', None), 'prepare_context'):
+            if den is not None:
+                return None, None
             den, net = o.denoiser, o.model
-        elif isinstance(o, dict) and o:
-            extra = True                                      # **kwargs forwarded to the network: not the plain pair
-    return (den, net) if (den is not None and net is not None and not extra) else (None, None)
+        elif isinstance(o, dict):
+            if o:
+                return None, None                             # **additional_model_inputs forwarded to the network: not the plain pair
+        else:
+            return None, None                                 # a cell the reference lambda does not have
+    return (den, net) if den is not None else (None, None)
 
 
 class EulerEDMSampler:
-    """sampling.py:82-130,211-215.  `lanes`: the batch is split into that many independent sub-batches that run the whole loop
-    on their own HIP streams (their kernels interleave on the device: one lane's HBM-bound epilogues and norms overlap the
-    other's MFMA main loops); None follows LN3D_LANES (default 1).  Results do not depend on it beyond the bf16 tile choice."""
+    """sampling.py:82-130,211-215 (EDMSampler with gamma = 0 + the Euler step)."""
 
-    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, use_graph=None, lanes=None, **_):
+    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, use_graph=None, **_):
         assert s_churn == 0.0, "released config: gamma = 0 (deterministic)"
         self.num_steps = num_steps
         self.use_graph = use_graph            # None: follow LN3D_GRAPH
-        self.lanes = lanes
         self.guider = guider or VanillaCFG(6.5)
         self.discretization = discretization or LegacyDDPMDiscretization()
 
@@ -165,12 +193,8 @@ class EulerEDMSampler:
             den, net = _find_pair(denoiser)
         if net is None:
             return self._generic(denoiser, x, cond, uc, num_steps, trace)
-        lanes = self.lanes if self.lanes is not None else int(os.environ.get('LN3D_LANES', '1') or 1)
-        B = x.shape[0]
         uc = cond if uc is None else uc
-        if lanes <= 1 or B < 2 * lanes or trace is not None or x.device.type != 'cuda':
-            return self._fast(den, net, x, cond, uc, num_steps, trace)
-        return self._fast_lanes(den, net, x, cond, uc, num_steps, lanes)
+        return self._fast(den, net, x, cond, uc, num_steps, trace)
 
     # ------------------------------------------------------------------ generic: the reference loop, one closure call per step
     def _generic(self, denoiser, x, cond, uc, num_steps, trace):
@@ -235,13 +259,13 @@ class EulerEDMSampler:
         mod_step['mod'].copy_(mod_all['mod'][:mrows])
         st['t_dev'].fill_(float(st['quant'][0][1]))
         st['s_dev'].fill_(1.0)
-        side = torch.cuda.Stream(device=dev)
+        side = _capture_stream(dev)                      # ONE stream per device for warm-up and capture
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces, kernel attributes
+        with torch.cuda.stream(side):                     # warm-up outside the capture: workspaces (allocated and zeroed here, once), kernel attributes
             network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=side):
             eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=True)
         st['graph'] = {'graph': graph, 'eps': eps_g, 'mod_step': mod_step, 'mrows': mrows}
 
@@ -258,62 +282,12 @@ class EulerEDMSampler:
                 trace.append(st['x'].clone())
         return st['x']
 
-    def _fast_lanes(self, den, network, x, cond, uc, num_steps, lanes):
-        """`lanes` sub-batches, each the complete EulerEDM loop of its samples on its own stream.  The network keeps one workspace
-        per stream (dit_models_xformers.Workspace), the schedule's modulation rows are shared (read-only)."""
-        n = self.num_steps if num_steps is None else num_steps
-        dev = x.device
-        B = x.shape[0]
-        cur = torch.cuda.current_stream(dev)
-        bounds = [B * k // lanes for k in range(lanes + 1)]
-        sl = lambda d, a, b: {k: v[a:b] for k, v in d.items()}
-        streams = _lane_streams(dev, lanes)
-        # every sample of a step shares its timestep, so one table serves lanes of any size (rows == 1); otherwise per lane
-        sig_all = self.discretization(n, device="cpu")
-        mod_shared = self._mod_all(network, [den.quantize(sig_all[i]) for i in range(n)], n, bounds[1] - bounds[0])
-        shared_ok = mod_shared is None or mod_shared['rows'] == 1
-        sts = []
-        for k in range(lanes):
-            a, b = bounds[k], bounds[k + 1]
-            streams[k].wait_stream(cur)
-            with torch.cuda.stream(streams[k]):
-                st = self._prepare(den, network, x[a:b], sl(cond, a, b), sl(uc, a, b), n)
-                st['mod'] = mod_shared if shared_ok else self._mod_all(network, st['quant'], n, b - a)
-                sts.append(st)
-        # lanes that start together run the same kernel at the same time and keep doing so (identical work): a start offset
-        # (LN3D_LANE_SKEW_US per lane index, default a third of a DiT-L/2 layer) puts one lane's HBM-bound phases under another's MFMA loops
-        skew_us = float(os.environ.get('LN3D_LANE_SKEW_US', '150'))
-        if skew_us > 0:
-            for k in range(1, lanes):
-                with torch.cuda.stream(streams[k]):
-                    torch.cuda._sleep(int(skew_us * k * 2000))           # spin cycles at ~2 GHz
-        for i in range(n):
-            for k in range(lanes):
-                with torch.cuda.stream(streams[k]):
-                    self._step(network, sts[k], i, sts[k]['mod'])
-        out = torch.empty_like(x, dtype=torch.float32)
-        for k in range(lanes):
-            with torch.cuda.stream(streams[k]):
-                out[bounds[k]:bounds[k + 1]].copy_(sts[k]['x'])
-            cur.wait_stream(streams[k])
-        return out
+
+_CAPTURE_STREAMS = {}
 
 
-_LANE_STREAMS = {}
-
-
-def _lane_streams(dev, n, mask=None):
-    """The lanes' streams, created once per (device, count, mode).  mask (None: LN3D_LANE_MASK, default 'cu'):
-      'cu'   lane k owns every n-th CU of EVERY XCD (the GEMMs' XCD-aware tile walk keeps its meaning; weights are shared in each L2)
-      'xcd'  lane k owns whole XCDs (8 / n of them: private L2s)
-      'none' plain streams: the hardware dispatcher interleaves the lanes' workgroups over all CUs."""
-    mask = (mask or os.environ.get('LN3D_LANE_MASK') or 'cu').lower()
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n, mask)
-    if key not in _LANE_STREAMS:
-        if mask == 'none':
-            _LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
-        else:
-            cus = ops.device_cus()
-            own = (lambda i, k: (i // 8) % n == k) if mask == 'cu' else (lambda i, k: (i % 8) * n // 8 == k)
-            _LANE_STREAMS[key] = [ops.masked_stream([i for i in range(cus) if own(i, k)], dev) for k in range(n)]
-    return _LANE_STREAMS[key]
+def _capture_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _CAPTURE_STREAMS[key]

@@ -46,7 +46,7 @@ NULL_CALLS = {
     'ln3d_mesh_emit': (N, 8, F(1), N, N, N, N),
     'ln3d_groupnorm_swish': (N, N, N, N, N, 1, 64, 64, 32, F(1e-6), 1, N),
     'ln3d_im2col3x3': (N, N, 1, 8, 8, 64, 1, 576, N),
-    'ln3d_stream_create_cu_mask': (N, 1, N),
+    'ln3d_probe_mfma_bf16': (N, 1, 1, N),
     'ln3d_groupnorm_any': (N, N, N, N, N, N, N, 1, 16, 64, 32, F(1e-5), 1, N),
     'ln3d_im2col3x3_strided': (N, N, 1, 8, 8, 64, 2, 576, N),
     'ln3d_geglu': (N, N, I64(1), 64, N),
@@ -55,7 +55,7 @@ NULL_CALLS = {
     'ln3d_cl_to_nchw_f32': (N, N, 1, 12, 64, N),
     'ln3d_mix_prediction': (N, N, N, F(0.5), 1, 12, 64, N),
 }
-NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_device_cus', 'ln3d_stream_cu_count'}      # pure host queries
+NOT_A_KERNEL = {'ln3d_abi_version', 'ln3d_gemm_heads_norm_fusable', 'ln3d_device_cus'}      # pure host queries
 
 
 def test_every_entry_point_rejects_missing_buffers(hip_lib):
@@ -69,7 +69,7 @@ def test_every_entry_point_rejects_missing_buffers(hip_lib):
 
 
 def test_host_queries(hip_lib):
-    assert hip_lib.ln3d_abi_version() == 9
+    assert hip_lib.ln3d_abi_version() == 10
     # the fused qk-norm epilogue needs head-aligned tiles: 64-wide heads yes, 72-in-128 padded heads no
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3072, 768, 64, 64) == 1
     assert hip_lib.ln3d_gemm_heads_norm_fusable(12288, 3 * 16 * 128, 768, 72, 128) == 0

@@ -74,7 +74,7 @@ def test_released_launcher_values_of_checked_flags_pass():
               "--ae_classname", "vit.vit_triplane.RodinSR_256_fusionv6_ConvQuant_liteSR_dinoInit3DAttn_SD_B_3L_C_withrollout_withSD_D_ditDecoder")
     assert validate(a) == 'edm'                     # the sgm engine never reads predict_v / pred_type (the reference neither)
     with pytest.raises(SystemExit) as e:            # ... the guided_diffusion engines do: ModelMeanType.V belongs to the U-Net denoiser
-        validate(_args(False, "--predict_v", "True"))
+        validate(_args(False, "--create_dit", "true", "--predict_v", "True"))
     assert "epsilon only" in str(e.value)
     # sample_shapenet_*_t23d.sh: the U-Net, v-prediction with mixed prediction, DDIM 250
     shapenet = ("--create_dit", "false", "--trainer_name", "vpsde_crossattn", "--num_channels", "320", "--num_res_blocks", "2", "--num_heads", "8",
@@ -82,6 +82,18 @@ def test_released_launcher_values_of_checked_flags_pass():
                 "--denoise_in_channels", "12", "--denoise_out_channels", "12", "--roll_out", "false", "--predict_v", "True", "--pred_type", "v",
                 "--mixed_prediction", "True", "--use_ddim", "True", "--timestep_respacing", "ddim250")
     assert validate(_args(False, *shapenet)) == 'gd'
+    # r6: the second script's defaults are the reference's (create_dit False, roll_out False), so the launcher's own flag set -
+    # which passes neither - selects the U-Net with the 12-channel latent
+    bare = tuple(f for i, f in enumerate(shapenet) if f not in ("--create_dit", "--roll_out") and shapenet[i - 1] not in ("--create_dit", "--roll_out"))
+    a = _args(False, *bare)
+    assert a.create_dit is False and a.roll_out is False and validate(a) == 'gd'
+    assert _args(True).create_dit is True and _args(True).roll_out is True
+    # r6: the second script's defaults are the reference's (create_dit False, roll_out False), so the launcher's own flag set -
+    # which passes neither - selects the U-Net with the 12-channel latent
+    bare = tuple(f for i, f in enumerate(shapenet) if f not in ("--create_dit", "--roll_out") and shapenet[i - 1] not in ("--create_dit", "--roll_out"))
+    a = _args(False, *bare)
+    assert a.create_dit is False and a.roll_out is False and validate(a) == 'gd'
+    assert _args(True).create_dit is True and _args(True).roll_out is True
     with pytest.raises(SystemExit) as e:            # v-prediction without the mixing branch: the reference's p_mean_variance asserts
         validate(_args(False, *[("False" if f == "True" and shapenet[i - 1] == "--mixed_prediction" else f) for i, f in enumerate(shapenet)]))
     assert "needs --mixed_prediction" in str(e.value)

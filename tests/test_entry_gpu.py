@@ -19,14 +19,15 @@ SMALL = "--arch_dit_decoder DiT2-B/2 --num_samples 2 --sample_steps 4 --image_si
     (True, "--dit_model_arch DiT-PixArt-MV-B/2 --i23d true --trainer_name flow_matching --num_mv_views 2"),
     (True, "--dit_model_arch DiT-B/2 --i23d true --trainer_name flow_matching --unconditional_guidance_scale 4.0"),      # plain DiT_I23D
     (True, "--dit_model_arch DiT-PixelArt-B/2 --trainer_name flow_matching --unconditional_guidance_scale 4.0"),   # T23D flow matching
-    (False, "--dit_model_arch DiT-B/2 --trainer_name adm --timestep_respacing 4"),
-    (False, "--dit_model_arch DiT-B/2 --trainer_name vpsde_crossattn --use_ddim true --timestep_respacing ddim4 --unconditional_guidance_scale 3.0"),
+    (False, "--create_dit true --roll_out true --dit_model_arch DiT-B/2 --trainer_name adm --timestep_respacing 4"),
+    (False, "--create_dit true --roll_out true --dit_model_arch DiT-B/2 --trainer_name vpsde_crossattn --use_ddim true --timestep_respacing ddim4 --unconditional_guidance_scale 3.0"),
     # the U-Net denoiser (ShapeNet launcher flags at a small width): v-prediction + mixed prediction, DDIM with CFG / ancestral sampling
     (False, "--create_dit false --trainer_name vpsde_crossattn --num_channels 128 --num_res_blocks 1 --num_heads 4 --channel_mult 1,2 "
             "--attention_resolutions 32,16 --denoise_in_channels 12 --denoise_out_channels 12 --roll_out false --predict_v true --pred_type v "
             "--mixed_prediction true --use_ddim true --timestep_respacing ddim4 --unconditional_guidance_scale 2.0"),
-    (False, "--create_dit false --trainer_name adm --num_channels 128 --num_res_blocks 1 --num_heads 4 --channel_mult 1,2 "
-            "--attention_resolutions 16 --use_spatial_transformer false --timestep_respacing 4"),
+    # the second script's own defaults select the U-Net (create_dit False, roll_out False: guided_diffusion/script_util.py:123,132)
+    (False, "--trainer_name adm --num_channels 128 --num_res_blocks 1 --num_heads 4 --channel_mult 1,2 "
+            "--attention_resolutions 16 --use_spatial_transformer false --timestep_respacing 4 --denoise_in_channels 12 --denoise_out_channels 12"),
 ])
 def test_entry_points_run(hip_lib, tmp_path, objaverse, flags):
     args = create_argparser(objaverse).parse_args((SMALL + " " + flags + f" --logdir {tmp_path}").split())

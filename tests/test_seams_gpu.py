@@ -352,29 +352,3 @@ def test_edm_sampler_takes_the_reference_positional_signature(hip_lib):
     assert torch.equal(yd, ye)
 
 
-@pytest.mark.parametrize("mask", ["none", "cu", "xcd"])
-def test_edm_sampler_lanes_match_the_single_stream_loop(hip_lib, monkeypatch, mask):
-    """lanes=2: two half-batches on their own HIP streams (plain, or restricted to disjoint halves of the compute units through
-    ln3d_stream_create_cu_mask), per-stream workspaces.  A sample's result may differ from the single-stream run only through the
-    GEMM tile chosen for the smaller row count / CU count (bf16-level), and is repeatable."""
-    from ln3diff_amd import ops
-    from ln3diff_amd.sgm.sampling import EulerEDMSampler, DiscreteDenoiser, VanillaCFG, _lane_streams
-    monkeypatch.setenv('LN3D_LANE_MASK', mask)
-    m, z, cond, uc = _edm_setup(B=4)
-    run = lambda lanes: EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5), lanes=lanes)(DiscreteDenoiser().bind(m), z.clone(), cond, uc)
-    y1, y2, y2b = run(1), run(2), run(2)
-    torch.cuda.synchronize()
-    e = rel_l2(y2, y1)
-    print('lanes 2 (%s) vs 1' % mask, e)
-    assert e < 2e-3, e
-    assert torch.equal(y2, y2b)
-    half = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5), lanes=1)(
-        DiscreteDenoiser().bind(m), z[2:].clone(), {'crossattn': cond['crossattn'][2:]}, {'crossattn': uc['crossattn'][2:]})
-    streams = _lane_streams(z.device, 2)
-    total = ops.device_cus()
-    if mask == 'none':
-        assert torch.equal(y2[2:], half)             # a lane IS the single-stream loop of its sub-batch
-        assert all(ops.stream_cu_count(s) == total for s in streams)
-    else:
-        assert rel_l2(y2[2:], half) < 2e-3
-        assert [ops.stream_cu_count(s) for s in streams] == [total // 2, total // 2] and ops.stream_cu_count() == total
