@@ -1027,6 +1027,261 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
   staged_epilogue<EPI, NI, NJ, (NW <= 8), kPre>(p, acc, smem + wid * 8192, f0 + wf * 32 * NI, t0 + wt * 32 * NJ, lane, xpre, re_pre, have_pre);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// r6: PERSISTENT one-wave-per-SIMD kernel ("p4", cfg 16).  256f x 256t tiles, 4 waves x (128f x 128t) with the 256 accumulators in
+// AGPRs (the cfg-13 K loop: 64 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces per K stage of 64), ONE workgroup per CU walking its tiles.
+// Why (profiles/r6_gemm.md): at K = 1024 a tile's loop is 33.8 k cycles (97 % of its MFMA bound), and the epilogue of a non-persistent
+// kernel - 100 MB of bf16 written by all CUs at once with the matrix pipe idle - costs 22 - 30 us of a ~105 us fc1 launch.  The store
+// path of a CU takes ~12 B / cycle for 16-byte-per-lane stores whatever the HBM does, so the stores have to run UNDER a K loop:
+//  * the epilogue only computes: accumulators -> (+ bias, GELU) -> bf16, the 4-feature quads of lanes l and l + 32 exchanged with
+//    v_permlane32_swap so that a lane holds 8 consecutive features of its token (one 16-byte store, no LDS staging - the ring already
+//    belongs to the next tile), the packed tile parked in 128 VGPRs;
+//  * the parked tile is stored from inside the NEXT tile's K loop, 3 stores in the third substep of eight stages (the first five and
+//    the last three, which are compile-time positions); the vector-memory counter retires in order, so those stages' rendezvous is
+//    `vmcnt(3)` - every DMA piece is older than the stores - and the stores have a whole stage to land before the next `vmcnt(0)`;
+//  * the next tile's first two K stages (and its bias row, a 1 KB LDS image) are DMA'd while this tile's last two stages multiply;
+//  * every tile runs the same code (the last tile "prefetches" itself: 128 KB of wasted fill per workgroup, no second code path).
+// Requires M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 512 (interior tiles only: the launcher falls back otherwise).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_p4_kernel(GemmP p) {
+  constexpr int NI = 4, NJ = 4, NM = 16, NR = 8;
+  constexpr int BF = 256, BT = 256, WB = BF * 128, STAGEB = (BF + BT) * 128, NPW = 16;
+  constexpr int BIASB = 2 * STAGEB;                         // two 1 KB bias images (tile parity) above the ring
+  constexpr int D1 = 8, LH = 12;                            // DMA pieces of a stage: [0, D1) behind the barrier two stages ahead, [D1, LH) / [LH, NPW) in the next stage's first two substeps
+  static_assert(EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF, "p4 epilogues");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wid >> 1, wt = wid & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nft = p.N / BF, ntt = p.M / BT, ntiles = nft * ntt;
+  const int G = gridDim.x;
+  auto tile_of = [&](int b, int& ft, int& tt) __attribute__((always_inline)) {
+    const int xcd = b & 7, slot = b >> 3;
+    if ((ntt & 7) == 0 && (nft & 3) == 0) {                 // an XCD owns ntt/8 token panels and walks the feature tiles in groups of 4
+      const int rows = ntt >> 3;
+      const int g = slot / (rows * 4), rem = slot - g * rows * 4;
+      ft = g * 4 + (rem & 3);
+      tt = xcd * rows + (rem >> 2);
+    } else {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+      ft = tile % nft; tt = tile / nft;
+    }
+  };
+  // lane offsets of the wave's 16 DMA pieces (8 W row groups, 8 X row groups): the same for every tile (interior tiles only)
+  const int r8 = lane >> 3;
+  // piece q covers rows 8 (8 wid + (q & 7)) + r8 of its operand tile: the (q & 7) term rides on the scalar base (8 rows = 8 ld bytes * 2),
+  // the swizzle chunk only depends on ((row >> 1) & 7) = ((4 (q & 7) + (r8 >> 1)) & 7): pieces of equal parity share the lane offset
+  uint32_t soff[2][2];                                      // [operand][q & 1]
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rt = 8 * (wid * 8 + h) + r8;
+      const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
+      soff[o][h] = (uint32_t)(((int64_t)(8 * wid * 8 + r8) * (o == 0 ? p.ldw : p.ldx) + chunk * 8) * 2);
+    }
+  const int64_t ld8w = 8 * p.ldw * 2, ld8x = 8 * p.ldx * 2;   // bytes per 8 rows
+  const int dW0 = wid * 8 * 1024, dX0 = WB + wid * 8 * 1024;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+#define P_ISSUE(WP, XP, slot, q) lds_dma16_s(((q) < 8 ? (WP) + ((q) & 7) * ld8w : (XP) + ((q) & 7) * ld8x), soff[(q) >> 3][(q) & 1], lds0 + (slot) * STAGEB + ((q) < 8 ? dW0 + (q) * 1024 : dX0 + ((q) - 8) * 1024))
+  const int key = (l31 >> 1) & 7;
+  const int a_row = (wf * 128 + l31) * 128;
+  const int b_row = WB + (wt * 128 + l31) * 128;
+#define P_RDA(slot, ks, i) (*reinterpret_cast<const bf16x8*>(smem + (slot) * STAGEB + a_row + (i) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+#define P_RDB(slot, ks, j) (*reinterpret_cast<const bf16x8*>(smem + (slot) * STAGEB + b_row + (j) * 4096 + (((2 * (ks) + hi) ^ key) << 4)))
+#define P_MMA(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], acc[(n) / NJ][(n) % NJ], 0, 0, 0)
+#define P_MMA0(FA, FB, n) acc[(n) / NJ][(n) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[(n) / NJ], FB[(n) % NJ], kZero16, 0, 0, 0)
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // parked output of the previous tile: entry (j, i, m) = 8 features [32 i + 16 m + 8 hi, + 8) of token 32 j + l31 of the wave's sub-tile
+  uint4 pend[24];                                            // token blocks 1 .. 3 (block 0 is stored from the epilogue: 128 parked VGPRs spilled)
+  char* pbase = nullptr;                                     // lane address of entry (0, 0, 0) in the previous tile's output
+  bool have = false;                                         // wave-uniform
+  const int64_t jstride = (int64_t)32 * p.ldo * 2;
+#define P_STORE(j, k) *reinterpret_cast<uint4*>(pbase + (j) * jstride + ((k) >> 1) * 64 + ((k) & 1) * 32) = pend[((j) - 1) * 8 + (k)]
+#define P_STOREQ(q) P_STORE(1 + (q) / 8, (q) % 8)          // parked entry q = 0..23
+  // substep: multiply (af, CB) while the next substep (rslot, ks2) is read: the token fragments into the other set NB (slots 1, 2, 4, 5),
+  // the weight fragments IN PLACE - af[i] is last used by MFMA 4 i + 3 and next by MFMA 4 i of the following substep, 13 slots later, so
+  // one register set serves (16 VGPRs that the parked output tile needs).  LATE: DMA pieces [L0, L1) of the NEXT stage into the other
+  // slot; SJ >= 0: parked stores 3 SJ .. 3 SJ + 2, one behind every fourth MFMA; ZERO: the tile's first substep multiplies into C = 0;
+  // SYNC: the stage's rendezvous sits behind the first MFMA (the reads then come from the other slot, which it publishes)
+#define P_PHASE(CB, NB, rslot, ks2, RD, LATE, WL, XL, dslot, L0, L1, SJ, ZERO, SYNC, FILL, WF, XF, fslot)  \
+  _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                        \
+    if (ZERO) { P_MMA0(af, CB, n); } else { P_MMA(af, CB, n); }                                           \
+    if ((SYNC) && n == 0) {                                                                               \
+      if ((SJ) >= 0 && have) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }                         \
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                           \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                 \
+      __builtin_amdgcn_s_barrier();                                                                       \
+    }                                                                                                     \
+    if (RD) {                                                                                             \
+      if ((n & 3) == 3) af[n >> 2] = P_RDA(rslot, ks2, n >> 2);                                           \
+      else if (n == 1 || n == 2) NB[n - 1] = P_RDB(rslot, ks2, n - 1);                                    \
+      else if (n == 4 || n == 5) NB[n - 2] = P_RDB(rslot, ks2, n - 2);                                    \
+    }                                                                                                     \
+    if (LATE) {                                                                                           \
+      _Pragma("unroll") for (int d = (L0); d < (L1); ++d)                                                 \
+          if ((d - (L0)) * NM / ((L1) - (L0)) == n) P_ISSUE(WL, XL, dslot, d);                            \
+    }                                                                                                     \
+    if (FILL) {                                                                                           \
+      _Pragma("unroll") for (int d = 0; d < D1; ++d)                                                      \
+          if (1 + d * (NM - 1) / D1 == n) P_ISSUE(WF, XF, fslot, d);                                      \
+    }                                                                                                     \
+    if (!(SYNC) && (SJ) >= 0 && (n & 3) == 1 && n < 12) { if (have) P_STOREQ(3 * ((SJ) < 0 ? 0 : (SJ)) + (n >> 2)); } \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  }
+  // One K stage on `slot`.  LATE: pieces [D1, NPW) of the next stage (sources WL / XL) go into the other slot during the first two
+  // substeps; the third substep carries the parked stores of group SJ (if any).  Behind the first MFMA of the last substep: own DMAs
+  // of the next stage landed - vmcnt(3) when this stage issued stores (they are the 3 youngest operations; the counter retires in
+  // order), else vmcnt(0) -, own fragment reads retired, barrier; then the first fragments of the next stage are read (PRE) and pieces
+  // [0, D1) of the stage after it (sources WF / XF) go into THIS slot, which the barrier just retired.
+#define P_STAGE(slot, LATE, WL, XL, WF, XF, SJ, ZERO, PRE)                                                \
+  {                                                                                                       \
+    P_PHASE(b0, b1, slot, 1, true, LATE, WL, XL, (slot) ^ 1, D1, LH, -1, ZERO, false, false, WF, XF, slot);      \
+    P_PHASE(b1, b0, slot, 2, true, LATE, WL, XL, (slot) ^ 1, LH, NPW, -1, false, false, false, WF, XF, slot);    \
+    P_PHASE(b0, b1, slot, 3, true, false, WL, XL, (slot) ^ 1, 0, 1, SJ, false, false, false, WF, XF, slot);      \
+    P_PHASE(b1, b0, (slot) ^ 1, 0, PRE, false, WL, XL, (slot) ^ 1, 0, 1, SJ, false, true, true, WF, XF, slot);   \
+  }
+
+  f32x16 acc[NI][NJ];
+  bf16x8 af[NI], b0[NJ], b1[NJ];
+  const int ns = p.K / 64;
+  const int64_t ldw2 = p.ldw * 2, ldx2 = p.ldx * 2;
+
+  int vb = blockIdx.x, ft, tt;
+  tile_of(vb, ft, tt);
+  const char* Wc = reinterpret_cast<const char*>(p.W) + (int64_t)ft * BF * ldw2;
+  const char* Xc = reinterpret_cast<const char*>(p.X) + (int64_t)tt * BT * ldx2;
+  int par = 0;                                              // bias image of the current tile
+  // prologue: both stages of the first tile and its bias row, landed before the loop
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) P_ISSUE(Wc, Xc, 0, q);
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) P_ISSUE(Wc + 128, Xc + 128, 1, q);
+  const uint32_t boff = (uint32_t)lane * 16;
+  if (p.bias) { if (wid == 0) lds_dma16_s(p.bias + ft * BF, boff, lds0 + BIASB); }
+  else if (wid < 2) *reinterpret_cast<float4*>(smem + BIASB + wid * 1024 + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);                        // nothing but LDS reads pending inside the loop (kernel-argument s_loads retired)
+
+  for (;;) {
+    const int vbn = vb + G;
+    const bool has_next = vbn < ntiles;
+    int ftn, ttn;
+    tile_of(has_next ? vbn : vb, ftn, ttn);
+    const char* Wn = reinterpret_cast<const char*>(p.W) + (int64_t)ftn * BF * ldw2;
+    const char* Xn = reinterpret_cast<const char*>(p.X) + (int64_t)ttn * BT * ldx2;
+    uint64_t tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+    if constexpr ((LN3D_RING_ABL & 8) != 0) tm0 = __builtin_amdgcn_s_memtime();
+    // first fragments of this tile (its stage 0 landed and was published by the previous tile's last rendezvous / the prologue): read
+    // here rather than under the last stage, so that 32 VGPRs are not live across the epilogue (they spilled)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) af[i] = P_RDA(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b0[j] = P_RDB(0, 0, j);
+    // stages 0 .. 4 and ns - 3 .. ns - 1 are compile-time positions: each carries 3 of the previous tile's 24 parked stores
+    P_STAGE(0, false, Wc, Xc, Wc + 2 * 128, Xc + 2 * 128, 0, true, true);                                          // s = 0: C = 0
+    if constexpr ((LN3D_RING_ABL & 8) != 0) tm1 = __builtin_amdgcn_s_memtime();
+    P_STAGE(1, true, Wc + 2 * 128, Xc + 2 * 128, Wc + 3 * 128, Xc + 3 * 128, 1, false, true);
+    P_STAGE(0, true, Wc + 3 * 128, Xc + 3 * 128, Wc + 4 * 128, Xc + 4 * 128, 2, false, true);
+    P_STAGE(1, true, Wc + 4 * 128, Xc + 4 * 128, Wc + 5 * 128, Xc + 5 * 128, 3, false, true);
+    P_STAGE(0, true, Wc + 5 * 128, Xc + 5 * 128, Wc + 6 * 128, Xc + 6 * 128, 4, false, true);
+    for (int s = 5; s + 3 < ns; s += 2) {
+      P_STAGE(1, true, Wc + (s + 1) * 128, Xc + (s + 1) * 128, Wc + (s + 2) * 128, Xc + (s + 2) * 128, -1, false, true);  // s odd
+      P_STAGE(0, true, Wc + (s + 2) * 128, Xc + (s + 2) * 128, Wc + (s + 3) * 128, Xc + (s + 3) * 128, -1, false, true);  // s + 1
+    }
+    P_STAGE(1, true, Wc + (ns - 2) * 128, Xc + (ns - 2) * 128, Wc + (ns - 1) * 128, Xc + (ns - 1) * 128, 5, false, true);  // s = ns - 3
+    P_STAGE(0, true, Wc + (ns - 1) * 128, Xc + (ns - 1) * 128, Wn, Xn, 6, false, true);                            // s = ns - 2: fills the next tile's stage 0
+    P_STAGE(1, true, Wn, Xn, Wn + 128, Xn + 128, 7, false, false);                                                  // s = ns - 1: ... and its stage 1; a0 / b0 = its first fragments
+#pragma unroll
+    for (int d = D1; d < NPW; ++d) P_ISSUE(Wn + 128, Xn + 128, 1, d);                                        // rest of the next tile's stage 1
+    if (p.bias && wid == 0) lds_dma16_s(p.bias + ftn * BF, boff, lds0 + BIASB + (par ^ 1) * 1024);
+    if constexpr ((LN3D_RING_ABL & 8) != 0) tm2 = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue: accumulators -> parked bf16 tile (registers only).  Bias is always added from the LDS image (zeros when the
+    // launch has none: a runtime test inside the unrolled block made hipcc round-trip all 256 accumulators through AGPR writes)
+    {
+      const float* bl = reinterpret_cast<const float*>(smem + BIASB + par * 1024) + wf * 128 + 4 * hi;
+      char* const nbase = reinterpret_cast<char*>((bf16_t*)p.out0 + (int64_t)(tt * BT + wt * 128 + l31) * p.ldo + ft * BF + wf * 128 + 8 * hi);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        ln3d_f32x2 bq[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float4 bA = *reinterpret_cast<const float4*>(bl + i * 32 + 16 * m), bB = *reinterpret_cast<const float4*>(bl + i * 32 + 16 * m + 8);
+          bq[m][0] = ln3d_f32x2{bA.x, bA.y}; bq[m][1] = ln3d_f32x2{bA.z, bA.w}; bq[m][2] = ln3d_f32x2{bB.x, bB.y}; bq[m][3] = ln3d_f32x2{bB.z, bB.w};
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            ln3d_f32x2 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ln3d_f32x2{acc[i][j][8 * m + 2 * e], acc[i][j][8 * m + 2 * e + 1]} + bq[m][e];
+            if constexpr (EPI == LN3D_EPI_GELU_ERF) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { float g0 = v[e].x, g1 = v[e].y; gelu_erf2(g0, g1); v[e] = ln3d_f32x2{g0, g1}; }
+            }
+            // lanes l / l + 32 exchange quads: lower lanes end up with features [16m, 16m + 8), upper lanes with [16m + 8, 16m + 16)
+            const uint32_t x0 = pack2bf(v[0].x, v[0].y), x1 = pack2bf(v[1].x, v[1].y), y0 = pack2bf(v[2].x, v[2].y), y1 = pack2bf(v[3].x, v[3].y);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            if (j == 0) *reinterpret_cast<uint4*>(nbase + i * 64 + m * 32) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            else pend[(j - 1) * 8 + i * 2 + m] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);           // one accumulator tile at a time: without it hipcc hoists the AGPR reads of the whole block and spills
+        }
+      }
+      pbase = nbase;
+      have = true;
+    }
+    if constexpr ((LN3D_RING_ABL & 8) != 0) {        // bench builds: per-wave stamps of every tile -> out2: [block][wave][tile k][4] = start, first stage done, loop done, epilogue done
+      tm3 = __builtin_amdgcn_s_memtime();
+      const int k = (vb - (int)blockIdx.x) / G;
+      if (lane == 0 && k < 16 && p.out2) {
+        uint32_t* tl = (uint32_t*)p.out2 + (((int64_t)blockIdx.x * 4 + wid) * 16 + k) * 4;
+        tl[0] = (uint32_t)tm0; tl[1] = (uint32_t)tm1; tl[2] = (uint32_t)tm2; tl[3] = (uint32_t)tm3;
+      }
+    }
+    if (!has_next) break;
+    vb = vbn; ft = ftn; tt = ttn; Wc = Wn; Xc = Xn; par ^= 1;
+  }
+  // the last tile's output; the self-prefetch of the last tile must not outlive the workgroup's LDS
+#pragma unroll
+  for (int j = 1; j < NJ; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P_STORE(j, k);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef P_ISSUE
+#undef P_RDA
+#undef P_RDB
+#undef P_MMA
+#undef P_STORE
+#undef P_STOREQ
+#undef P_MMA0
+#undef P_PHASE
+#undef P_STAGE
+}
+
+template <int EPI>
+static int launch_p4(const GemmP& p, hipStream_t s) {
+  constexpr int LDSB = 2 * (256 + 256) * 128 + 2048;
+  static_assert(LDSB <= 163840, "ring + bias images");
+  static AttrOnce attr_once;
+  if (attr_once.need())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+  const int ntiles = (p.N / 256) * (p.M / 256), cus = ln3d_stream_cus(s);
+  hipLaunchKernelGGL((gemm_bf16_p4_kernel<EPI>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDSB, s, p);
+  return ln3d_check_launch();
+}
+static bool p4_ok(const GemmP& p) {
+  return (p.M % 256) == 0 && (p.N % 256) == 0 && (p.K % 128) == 0 && p.K >= 512 && (p.ldo % 8) == 0 &&
+         ((uintptr_t)p.out0 & 15) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0);
+}
+
 template <int EPI, int NW, int WGT, int NI, int NJ>
 static int launch_ring64(const GemmP& p, hipStream_t s) {
   constexpr int BF = 32 * NI * (NW / WGT), BT = 32 * NJ * WGT;
@@ -1054,7 +1309,7 @@ static int launch(const GemmP& p, hipStream_t s) {
   return ln3d_check_launch();
 }
 
-// cfg 0 = 128x128 register-staged kernel; 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (8 waves), 12 = 384f x 192t (12 waves,
+// cfg 0 = 128x128 register-staged kernel; 16 = persistent 256f x 256t with 4 waves (r6); 7 = 256f x 256t, 8 = 128f x 384t, 9 = 256f x 192t (8 waves), 12 = 384f x 192t (12 waves,
 // 3 per SIMD), 14 = 128f x 192t (4 waves), 13 = 256f x 256t with 4 waves (r5: long-K GEMMs only, see pick_cfg).  r2's 384x192 / 8-wave variant (11) was
 // measured slower and is gone.
 template <int EPI>
@@ -1067,6 +1322,9 @@ static int run_cfg(const GemmP& p, hipStream_t s, int cfg) {
     case 9: return launch_ring64<EPI, 8, 2, 2, 3>(p, s);
     case 12: return launch_ring64<EPI, 12, 2, 2, 3>(p, s);
     case 14: return launch_ring64<EPI, 4, 2, 2, 3>(p, s);      // 128f x 192t, 4 waves, 80 KB: two workgroups per CU (the half-batch GEMMs)
+    case 16:   // r6: the persistent form of 13 (plain bf16 / erf-GELU epilogues, interior tiles only)
+      if constexpr (EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_GELU_ERF) { if (p4_ok(p)) return launch_p4<EPI>(p, s); }
+      return launch_ring64<EPI, 8, 4, 4, 2>(p, s);
     case 13:   // 256f x 256t with 4 waves: ONE wave per SIMD, 128 x 128 per wave, the 16 accumulator tiles in AGPRs (hipcc allocates them
                // there by itself: only MFMAs touch them inside the K loop).  Instantiated for the epilogues that have long-K users.
       if constexpr (EPI == LN3D_EPI_GATE_RES || EPI == LN3D_EPI_BF16 || EPI == LN3D_EPI_F32) return launch_ring64<EPI, 4, 2, 4, 4>(p, s);
@@ -1120,6 +1378,16 @@ static int pick_cfg(int M, int N, bool head_aligned = false, hipStream_t s = nul
   // In situ (same-box A/B of the configs[2] line, temporary switch removed): 11.60 -> 11.70 samples/s, golden check unchanged.
   if (best == 7 && K >= 2048 && best_tiles >= 2 * (int64_t)cus && (epi == LN3D_EPI_GATE_RES || epi == LN3D_EPI_BF16 || epi == LN3D_EPI_F32))
     best = 13;
+  // r6: the persistent one-wave-per-SIMD kernel (cfg 16) for the bf16 / erf-GELU epilogues when every CU gets >= 2 whole 256 x 256 tiles
+  // and the last round is >= 85 % full (DiT-L/2 fc1: 768 tiles = 3 rounds; I23D fc1: 12).  Sustained (3000-launch loops, profiles/r6_gemm.md):
+  // fc1 + GELU 102.8 -> 99.0 us, plain 94.0 -> 87.2, I23D fc1 + GELU 411.6 -> 398.0.  run_cfg falls back to cfg 7 when p4_ok() refuses.
+#ifndef LN3D_P4_AUTO
+#define LN3D_P4_AUTO 1      // bench builds: 0 = never pick cfg 16 by itself (same-box A/B of the whole line)
+#endif
+  if (LN3D_P4_AUTO && (epi == LN3D_EPI_BF16 || epi == LN3D_EPI_GELU_ERF) && (M % 256) == 0 && (N % 256) == 0 && (K % 128) == 0 && K >= 512) {
+    const int64_t t = (int64_t)(N / 256) * (M / 256), rounds = (t + cus - 1) / cus;
+    if (t >= 2 * (int64_t)cus && t * 100 >= rounds * cus * 85) best = 16;
+  }
   return best;
 }
 

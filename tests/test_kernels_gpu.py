@@ -11,7 +11,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x12", "x13", "x14"])
+@pytest.fixture(scope="module", params=["auto", "small", "x7", "x8", "x9", "x12", "x13", "x14", "x16"])
 def ops(hip_lib, request):
     """Every kernel test runs with the GEMM tile selection left to the library and forced to each tile config."""
     import os
@@ -73,6 +73,40 @@ def test_gemm_plain_epilogues(ops, M, N, K):
     o32 = torch.empty(M, N, device=dev)
     ops.gemm(xb, wb, b, ops.EPI_F32_SILU, o32, o16)
     assert rel_l2(o32, ref) < 2e-5 and rel_l2(o16.float(), torch.nn.functional.silu(ref)) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(8192, 4096, 512, True), (12288, 4096, 1024, True), (4096, 2048, 1152, False), (12288, 1024, 1024, True)])
+def test_gemm_persistent_tile_walk(hip_lib, auto_tile, monkeypatch, M, N, K, bias):
+    """r6: the persistent one-wave-per-SIMD kernel (cfg 16) over several tiles per workgroup (2, 3), under one round (the 1.0-tile case:
+    M 4096 x N 2048 = 128 tiles; N = 1024 x M 12288 = 192 tiles), without bias (zero image), K = 1152 (18 stages): bf16 and erf-GELU
+    epilogues against fp32 torch on the same bf16 operands, bit-identical to the non-persistent 256 x 256 tile (same summation order),
+    bit-repeatable; its output parked in registers and stored from inside the next tile's K loop must all arrive."""
+    from ln3diff_amd import ops as o
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * (1 + torch.arange(M)[:, None] / M)).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05 * (1 + torch.arange(K)[None, :] / K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    xb, wb = _bf(x), _bf(w)
+    ref = xb.float() @ wb.float().t() + (b if bias else 0.0)
+    outs = {}
+    for tile in ('x16', 'x7'):
+        monkeypatch.setenv('LN3D_GEMM_TILE', tile)
+        o.reload_env()
+        y = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        o.gemm(xb, wb, b, o.EPI_BF16, y)
+        yg = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        o.gemm(xb, wb, b, o.EPI_GELU_ERF, yg)
+        yg2 = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        o.gemm(xb, wb, b, o.EPI_GELU_ERF, yg2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all() and torch.isfinite(yg.float()).all()
+        assert rel_l2(y.float(), ref) < 4e-3 and rel_l2(yg.float(), torch.nn.functional.gelu(ref)) < 5e-3
+        assert torch.equal(yg, yg2)
+        outs[tile] = (y, yg)
+    monkeypatch.delenv('LN3D_GEMM_TILE')
+    o.reload_env()
+    assert torch.equal(outs['x16'][0], outs['x7'][0]) and torch.equal(outs['x16'][1], outs['x7'][1])
 
 
 def test_gemm_identity_asymmetric(ops):

@@ -1,6 +1,6 @@
 // Stand-alone bench + self-check of csrc/gemm_bf16.hip (no torch import: a fresh GPU box spends 1-2 minutes on that).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DLN3D_RING_VAR=n] [-DLN3D_RING_ABL=n] tools/gemm_bench.hip -o build/gemm_bench
-//   build/gemm_bench [rounds] [case-substring]
+//   build/gemm_bench [rounds] [case-substring] [launches per round = 20]
 // Every case: outputs hashed (FNV-1a over the raw bytes: variants that keep the summation order must agree bit for bit),
 // 4096 sampled outputs checked against an fp32 dot product of the same bf16 operands (plain / GELU / gate+residual epilogues),
 // then `rounds` timing rounds of 20 launches each (HIP events on the launch stream); min and median over the rounds.
@@ -49,6 +49,7 @@ struct Case { const char* name; int M, N, K, epi; int tokens; const char* tile; 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 3;
   const char* filt = argc > 2 ? argv[2] : "";
+  const int per_round = argc > 3 ? atoi(argv[3]) : 20;      // launches per timing round: 20 = a 2 ms burst at boost clocks, 2000+ = the sustained (power-capped) rate
   const Case cases[] = {
       {"fc1 GELU_ERF", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, nullptr},
       {"fc1 plain", 12288, 4096, 1024, LN3D_EPI_BF16, 768, nullptr},
@@ -75,6 +76,16 @@ int main(int argc, char** argv) {
       {"fc2 GATE_RES x14", 12288, 1024, 4096, LN3D_EPI_GATE_RES, 768, "x14"},
       {"fc2 plain x14", 12288, 1024, 4096, LN3D_EPI_BF16, 768, "x14"},
       {"square 8192 plain x14", 8192, 8192, 8192, LN3D_EPI_BF16, 8192, "x14"},
+      {"fc1 GELU x16 (persistent 4 waves)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x16"},
+      {"fc1 plain x16", 12288, 4096, 1024, LN3D_EPI_BF16, 768, "x16"},
+      {"qkv plain x16", 12288, 3072, 1024, LN3D_EPI_BF16, 768, "x16"},
+      {"proj plain x16", 12288, 1024, 1024, LN3D_EPI_BF16, 768, "x16"},
+      {"fc2 plain x16", 12288, 1024, 4096, LN3D_EPI_BF16, 768, "x16"},
+      {"square 8192 plain x16", 8192, 8192, 8192, LN3D_EPI_BF16, 8192, "x16"},
+      {"i23d fc1 GELU M49152 x16", 49152, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x16"},
+      {"i23d fc1 GELU M49152", 49152, 4096, 1024, LN3D_EPI_GELU_ERF, 768, nullptr},
+      {"small 512x512x256 plain x16", 512, 512, 256, LN3D_EPI_BF16, 512, "x16"},
+      {"odd tiles 1280x768x384 plain x16", 1280, 768, 384, LN3D_EPI_BF16, 1280, "x16"},
       {"fc1 GELU x13 (256x256, 4 waves)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x13"},
       {"fc1 plain x13", 12288, 4096, 1024, LN3D_EPI_BF16, 768, "x13"},
       {"qkv plain x13", 12288, 3072, 1024, LN3D_EPI_BF16, 768, "x13"},
@@ -123,7 +134,7 @@ int main(int argc, char** argv) {
       o0b = (size_t)M * N * 2; o1b = o2b = (size_t)B * H * 128 * 64 * 2; a.bias = nullptr;
       a.tokens = c.tokens; a.heads = H; a.head_dim = 64; a.ctx_keys = 77; a.ctx_pad = 128; a.ctx_scale = 0.125f;
     } else o0b = (size_t)M * N * (c.epi == LN3D_EPI_F32 ? 4 : 2);
-    const bool timeline = (LN3D_RING_ABL & 8) && c.epi == LN3D_EPI_BF16;
+    const bool timeline = (LN3D_RING_ABL & 8) && (c.epi == LN3D_EPI_BF16 || c.epi == LN3D_EPI_GELU_ERF);
     if (timeline) o2b = (size_t)8192 * 12 * 64 * 4 * 4;       // [block][wave][stage][4] stamps
     CK(hipMalloc(&o0, o0b)); if (o1b) CK(hipMalloc(&o1, o1b)); if (o2b) CK(hipMalloc(&o2, o2b));
     CK(hipMemsetAsync(o0, 0, o0b, st));
@@ -162,7 +173,29 @@ int main(int argc, char** argv) {
       }
       CK(hipFree(mi)); CK(hipFree(ni)); CK(hipFree(ref));
     }
-    if (timeline) {
+    if (timeline && c.tile && !strcmp(c.tile, "x16")) {
+      CK(hipMemsetAsync(o2, 0, o2b, st));
+      for (int w = 0; w < 50; ++w) ln3d_gemm_bf16(&a, st);            // sustained clock first
+      CK(hipMemsetAsync(o2, 0, o2b, st));
+      CK(hipEventRecord(e0, st)); ln3d_gemm_bf16(&a, st); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
+      std::vector<uint32_t> tl(o2b / 4); CK(hipMemcpy(tl.data(), o2, o2b, hipMemcpyDeviceToHost));
+      double first = 0, loop = 0, epi = 0, gap = 0, whole = 0; long nt = 0, ng = 0, nw = 0;
+      for (int b = 0; b < 256; ++b)
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t* q = &tl[(((size_t)b * 4 + w) * 16) * 4];
+          int last = -1;
+          for (int k = 0; k < 16; ++k) {
+            if (q[k * 4 + 3] == 0) break;
+            first += (double)(uint32_t)(q[k * 4 + 1] - q[k * 4 + 0]); loop += (double)(uint32_t)(q[k * 4 + 2] - q[k * 4 + 0]); epi += (double)(uint32_t)(q[k * 4 + 3] - q[k * 4 + 2]); ++nt;
+            if (k > 0) { gap += (double)(uint32_t)(q[k * 4 + 0] - q[(k - 1) * 4 + 3]); ++ng; }
+            last = k;
+          }
+          if (last >= 0) { whole += (double)(uint32_t)(q[last * 4 + 3] - q[0]); ++nw; }
+        }
+      printf("  p4 timeline %-22s: 1 launch %.1f us | per tile per wave (ticks): first stage %.0f, whole K loop %.0f, epilogue %.0f, between tiles %.0f | first tile start -> last epilogue end %.0f ticks, %ld tiles\n",
+             c.name, ms1 * 1000.f, first / nt, loop / nt, epi / nt, ng ? gap / ng : 0.0, whole / nw, nt);
+    } else if (timeline) {
       // one launch alone, timed, then the stamps: A = before the stage's waits, B = own DMAs landed + own reads retired, C = behind the barrier
       CK(hipMemsetAsync(o2, 0, o2b, st));
       CK(hipEventRecord(e0, st)); ln3d_gemm_bf16(&a, st); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
@@ -191,9 +224,9 @@ int main(int argc, char** argv) {
     for (int r = 0; r < rounds; ++r) {
       for (int i = 0; i < 2; ++i) ln3d_gemm_bf16(&a, st);
       CK(hipEventRecord(e0, st));
-      for (int i = 0; i < 20; ++i) ln3d_gemm_bf16(&a, st);
+      for (int i = 0; i < per_round; ++i) ln3d_gemm_bf16(&a, st);
       CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
-      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1000.f / 20);
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1000.f / per_round);
     }
     std::sort(ts.begin(), ts.end());
     const float tmin = ts[0], tmed = ts[ts.size() / 2];
