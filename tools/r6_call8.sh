@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+L=gpurun_out/r6_p4_static.log; : > $L
+timeout 300 build/gemm_bench_p4 2 "x16" >> $L 2>&1
+for r in 1 2; do
+for c in "fc1 GELU x16" "fc1 plain x16"; do
+echo "--- static" >> $L; timeout 300 build/gemm_bench_p4 3 "$c" 3000 >> $L 2>&1
+echo "--- dynamic" >> $L; timeout 300 build/gemm_bench_p4dyn 3 "$c" 3000 >> $L 2>&1
+done; done
+grep -v LN3D $L
