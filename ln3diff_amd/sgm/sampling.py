@@ -170,17 +170,29 @@ def _find_pair(denoiser):
 
 
 class EulerEDMSampler:
-    """sampling.py:82-130,211-215 (EDMSampler with gamma = 0 + the Euler step)."""
+    """sampling.py:82-130,211-215: EDMSampler + the Euler step.  The released configuration is s_churn = 0 (gamma = 0: deterministic);
+    s_churn / s_tmin / s_tmax / s_noise > 0 (r6) add the reference's noise injection: where s_tmin <= sigma_i <= s_tmax,
+    gamma = min(s_churn / (num_sigmas - 1), sqrt 2 - 1), sigma_hat = sigma_i (1 + gamma), x += randn * s_noise * sqrt(sigma_hat^2 -
+    sigma_i^2), and the denoiser runs at sigma_hat (quantised to the 1000-entry table for c_out / c_in / the timestep, the Euler step
+    itself on sigma_hat).  The draw of step i comes from `step_noise(i)` (a [B, ...] tensor; parity runs feed the recorded stream) or
+    torch.randn on the device."""
 
-    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, use_graph=None, **_):
-        assert s_churn == 0.0, "released config: gamma = 0 (deterministic)"
+    def __init__(self, num_steps=250, guider=None, discretization=None, s_churn=0.0, s_tmin=0.0, s_tmax=float('inf'), s_noise=1.0,
+                 use_graph=None, **_):
         self.num_steps = num_steps
         self.use_graph = use_graph            # None: follow LN3D_GRAPH
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = float(s_churn), float(s_tmin), float(s_tmax), float(s_noise)
         self.guider = guider or VanillaCFG(6.5)
         self.discretization = discretization or LegacyDDPMDiscretization()
 
+    def _gammas(self, sigmas):
+        """gamma per step (sampling.py:114-118): num_sigmas = len(sigmas) counts the appended zero."""
+        n = len(sigmas)
+        g = min(self.s_churn / (n - 1), 2 ** 0.5 - 1)
+        return [g if (self.s_churn > 0 and self.s_tmin <= float(sigmas[i]) <= self.s_tmax) else 0.0 for i in range(n - 1)]
+
     @torch.no_grad()
-    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None):
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
         """The reference's call (sampling.py:109): denoiser = the engine's closure (input, sigma, c) -> denoised; x [B,12,32,32]
         f32 device noise (consumed in place: returns the final latent); cond / uc dicts with 'crossattn'.
         Fast path (context K/V, the timestep sub-network of the whole schedule and the CFG + Euler update fused): taken when the
@@ -192,14 +204,22 @@ class EulerEDMSampler:
         else:
             den, net = _find_pair(denoiser)
         if net is None:
-            return self._generic(denoiser, x, cond, uc, num_steps, trace)
+            return self._generic(denoiser, x, cond, uc, num_steps, trace, step_noise)
         uc = cond if uc is None else uc
-        return self._fast(den, net, x, cond, uc, num_steps, trace)
+        return self._fast(den, net, x, cond, uc, num_steps, trace, step_noise)
 
     # ------------------------------------------------------------------ generic: the reference loop, one closure call per step
-    def _generic(self, denoiser, x, cond, uc, num_steps, trace):
+    def _churn(self, x, sig, gamma, i, step_noise):
+        """x += randn * s_noise * sqrt(sigma_hat^2 - sigma^2) in place; returns sigma_hat (sampling.py:96-99)."""
+        sig_hat = sig * (gamma + 1.0)
+        eps = step_noise(i).to(x.device).float().contiguous() if step_noise is not None else torch.randn(x.shape, device=x.device)
+        ops.lincomb(x, [eps], [self.s_noise * (sig_hat ** 2 - sig ** 2) ** 0.5], x)
+        return sig_hat
+
+    def _generic(self, denoiser, x, cond, uc, num_steps, trace, step_noise=None):
         n = self.num_steps if num_steps is None else num_steps
         sigmas = self.discretization(n, device="cpu")
+        gammas = self._gammas(sigmas)
         uc = cond if uc is None else uc
         x = (x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))).contiguous()
         B = x.shape[0]
@@ -207,6 +227,8 @@ class EulerEDMSampler:
         sc = float(self.guider.scale)
         for i in range(n):
             sig, nxt = float(sigmas[i]), float(sigmas[i + 1])
+            if gammas[i] > 0:
+                sig = self._churn(x, sig, gammas[i], i, step_noise)
             den = denoiser(*self.guider.prepare_inputs(x, s_in * sig, cond, uc)).contiguous().float()
             # guider + to_d + euler_step in one combination: x + dt/sigma * (x - (x_u + s (x_c - x_u)))
             r = (nxt - sig) / sig
@@ -220,9 +242,11 @@ class EulerEDMSampler:
         sigmas = self.discretization(n, device="cpu")
         B, dev = x.shape[0], x.device
         ctx = torch.cat((uc['crossattn'], cond['crossattn']), 0).to(dev)      # VanillaCFG: [uc, c]
-        st = {'cache': network.prepare_context(ctx), 'sigmas': sigmas, 'B': B,
+        gammas = self._gammas(sigmas)
+        st = {'cache': network.prepare_context(ctx), 'sigmas': sigmas, 'B': B, 'gammas': gammas,
               't_dev': torch.empty(2 * B, device=dev, dtype=torch.float32), 's_dev': torch.empty(2 * B, device=dev, dtype=torch.float32),
-              'quant': [den.quantize(sigmas[i]) for i in range(n)]}
+              # the denoiser sees sigma_hat = sigma (1 + gamma), quantised to its table (denoiser.py:66-78)
+              'quant': [den.quantize(float(sigmas[i]) * (gammas[i] + 1.0)) for i in range(n)]}
         st['x'] = x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
         return st
 
@@ -233,8 +257,11 @@ class EulerEDMSampler:
         t_table = torch.tensor([float(q[1]) for q in quant], dtype=torch.float32)[:, None].expand(n, 2 * B)
         return network.prepare_timesteps(t_table)
 
-    def _step(self, network, st, i, mod_all):
+    def _step(self, network, st, i, mod_all, step_noise=None):
         sig, idx = st['quant'][i]
+        gamma = st['gammas'][i]
+        if gamma > 0:
+            sig_hat = self._churn(st['x'], float(st['sigmas'][i]), gamma, i, step_noise)
         c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
         st['t_dev'].fill_(float(idx))
         st['s_dev'].fill_(c_in)
@@ -247,7 +274,15 @@ class EulerEDMSampler:
             eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_all, i), cfg_twins=True)
         else:
             eps2 = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], cfg_twins=True)
-        ops.edm_euler_step(st['x'], eps2, sig, float(st['sigmas'][i + 1]), float(self.guider.scale))
+        if gamma > 0:
+            # denoised = x - sig_q (eps_u + s (eps_c - eps_u)); d = (x - denoised) / sigma_hat; x += d (sigma_next - sigma_hat): sig_q (the table
+            # entry c_out uses) and sigma_hat differ here, which the fused kernel's single sigma cannot express - one linear combination instead
+            B, sc = st['B'], float(self.guider.scale)
+            r = (float(st['sigmas'][i + 1]) - sig_hat) / sig_hat * sig
+            e2 = eps2.reshape(2, -1)
+            ops.lincomb(st['x'], [e2[0].reshape(st['x'].shape), e2[1].reshape(st['x'].shape)], [r * (1.0 - sc), r * sc], st['x'])
+        else:
+            ops.edm_euler_step(st['x'], eps2, sig, float(st['sigmas'][i + 1]), float(self.guider.scale))
 
     def _capture(self, network, st, mod_all, dev):
         """Optional HIP-graph replay of the network evaluation (LN3D_GRAPH=1 or use_graph=True): the ~220 launches of a forward
@@ -269,7 +304,7 @@ class EulerEDMSampler:
             eps_g = network(st['x'], st['t_dev'], context_cache=st['cache'], in_scale=st['s_dev'], mod_cache=(mod_step, 0), cfg_twins=True)
         st['graph'] = {'graph': graph, 'eps': eps_g, 'mod_step': mod_step, 'mrows': mrows}
 
-    def _fast(self, den, network, x, cond, uc, num_steps, trace):
+    def _fast(self, den, network, x, cond, uc, num_steps, trace, step_noise=None):
         n = self.num_steps if num_steps is None else num_steps
         st = self._prepare(den, network, x, cond, uc, n)
         mod_all = self._mod_all(network, st['quant'], n, st['B'])
@@ -277,7 +312,7 @@ class EulerEDMSampler:
         if want_graph and mod_all is not None and n > 2:
             self._capture(network, st, mod_all, x.device)
         for i in range(n):
-            self._step(network, st, i, mod_all)
+            self._step(network, st, i, mod_all, step_noise)
             if trace is not None:
                 trace.append(st['x'].clone())
         return st['x']

@@ -68,14 +68,24 @@ def edm_denoise_cfg(net, x, sigma, cond, uc, scale, table):
     return x_u + scale * (x_c - x_u)
 
 
-def edm_euler_sample(net, z, cond, uc, num_steps=250, scale=6.5, trace=None):
-    """EulerEDMSampler.__call__ with s_churn=0 (gamma=0: deterministic after z)."""
+def edm_euler_sample(net, z, cond, uc, num_steps=250, scale=6.5, trace=None, s_churn=0.0, s_tmin=0.0, s_tmax=float('inf'), s_noise=1.0,
+                     step_noise=None):
+    """EulerEDMSampler.__call__ (sgm/modules/diffusionmodules/sampling.py:82-130,211-215).  s_churn = 0: gamma = 0, deterministic after z.
+    s_churn > 0 (r6): gamma_i = min(s_churn / (num_sigmas - 1), sqrt 2 - 1) where s_tmin <= sigma_i <= s_tmax; sigma_hat = sigma (1 + gamma),
+    x += randn * s_noise * sqrt(sigma_hat^2 - sigma^2) before the denoiser runs at sigma_hat; step_noise(i) supplies the draw of step i."""
     sigmas = legacy_ddpm_sigmas(num_steps)
     table = discrete_denoiser_table()
     x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     s_in = x.new_ones([x.shape[0]])
+    num_sigmas = len(sigmas)
     for i in range(len(sigmas) - 1):
         sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        gamma = min(s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+        if gamma > 0:
+            sigma_hat = sigma * (gamma + 1.0)
+            eps = (step_noise(i) if step_noise is not None else torch.randn_like(x)) * s_noise
+            x = x + eps * ((sigma_hat ** 2 - sigma ** 2) ** 0.5).view(-1, *([1] * (x.ndim - 1)))
+            sigma = sigma_hat
         den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
         sb = sigma.view(-1, *([1] * (x.ndim - 1)))
         d = (x - den) / sb

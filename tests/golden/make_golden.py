@@ -191,6 +191,26 @@ def sec_samplers():
         save(f'edm_tiny_{steps}', final=y_ref, first=trace[0], mid=trace[steps // 2],
              sigmas=sig_ref, idx_first=seen_t[0], idx_last=seen_t[-1])
 
+    # --- r6: the same sampler with noise injection (s_churn > 0: sampling.py:82-130); the reference draws randn_like(x) per churned step
+    steps, churn = 10, dict(s_churn=4.0, s_tmin=0.5, s_tmax=10.0, s_noise=1.003)
+    sampler = EulerEDMSampler(discretization_config=dc, num_steps=steps,
+                              guider_config={'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG', 'params': {'scale': 6.5}},
+                              device='cpu', **churn)
+    seen_t = []
+    torch.manual_seed(11)
+    y_ref = sampler(lambda x, s, c: den(net, x, s, c), z.clone(), cond, uc)
+    sig = osamp.legacy_ddpm_sigmas(steps)
+    churned = [i for i in range(steps) if churn['s_tmin'] <= float(sig[i]) <= churn['s_tmax']]
+    torch.manual_seed(11)
+    draws = {i: torch.randn(B, 12, 32, 32) for i in churned}                 # the reference's RNG stream, in step order
+    trace = []
+    y_or = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2), z.clone(), cond, uc, steps, 6.5, trace,
+                                  step_noise=lambda i: draws[i], **churn)
+    check(f'EulerEDM {steps} steps with s_churn final latent', y_or, y_ref, 2e-4)
+    print('   churned steps', churned, 'timesteps seen', [int(t[0]) for t in seen_t])
+    save('edm_tiny_10_churn', final=y_ref, mid=trace[steps // 2], churned=np.array(churned), noise_seed=np.array(11),
+         idx_seen=np.array([int(t[0]) for t in seen_t]), **{k: np.array(v) for k, v in churn.items()})
+
     # --- guided_diffusion p_sample_loop '250'
     from guided_diffusion import gaussian_diffusion as gd
     from guided_diffusion.respace import SpacedDiffusion, space_timesteps

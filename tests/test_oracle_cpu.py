@@ -95,6 +95,20 @@ def test_oracle_edm_euler_matches_reference_golden():
     assert abs(float(s250[0]) - 14.6146) < 1e-3 and abs(float(s250[249]) - 0.0586) < 1e-3 and float(s250[250]) == 0
 
 
+def test_oracle_edm_euler_with_churn_matches_reference_golden():
+    """r6: s_churn / s_tmin / s_tmax / s_noise (sampling.py:82-130) through the reference's own sampler, its RNG stream re-drawn from the seed."""
+    g = golden('edm_tiny_10_churn')
+    sd = _sd_from_manifest(golden('t23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (2, 77, 768), 41), 'vector': synth_input('v', (2, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    torch.manual_seed(int(g['noise_seed']))
+    draws = {int(i): torch.randn(2, 12, 32, 32) for i in g['churned']}
+    y = osamp.edm_euler_sample(lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2), z, cond, uc, 10, 6.5, None, step_noise=lambda i: draws[i],
+                               s_churn=float(g['s_churn']), s_tmin=float(g['s_tmin']), s_tmax=float(g['s_tmax']), s_noise=float(g['s_noise']))
+    assert 0 < len(draws) < 10 and rel_l2(y, g['final']) < 1e-4
+
+
 @pytest.mark.parametrize("method,steps", [('heun', 10), ('midpoint', 10), ('rk4', 6)])
 def test_oracle_flow_fixed_grid_matches_reference_golden(method, steps):
     g = golden(f'flow_tiny_{method}{steps}')

@@ -40,6 +40,41 @@ def test_edm_euler_cfg_vs_reference_golden(hip_lib, steps):
     assert e0 < 2e-3 and e1 < 1e-2, (e0, em, e1)
 
 
+def test_edm_euler_with_churn_vs_reference_golden(hip_lib):
+    """r6: EDMSampler's noise injection (s_churn, s_tmin, s_tmax, s_noise; sampling.py:82-130): fast path (fused network loop) and generic
+    path (opaque closure) against the reference's own sampler, the draws re-created from its seed; the timesteps the network sees are the
+    quantised sigma_hat's."""
+    from ln3diff_amd.sgm.sampling import EulerEDMSampler, DiscreteDenoiser, VanillaCFG
+    from ln3diff_amd.synth import synth_input
+    g = golden('edm_tiny_10_churn')
+    m = _tiny()
+    z = synth_input('z', (2, 12, 32, 32), 41).cuda()
+    cond = {'crossattn': synth_input('c', (2, 77, 768), 41).cuda()}
+    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+    torch.manual_seed(int(g['noise_seed']))
+    draws = {int(i): torch.randn(2, 12, 32, 32) for i in g['churned']}
+    kw = dict(s_churn=float(g['s_churn']), s_tmin=float(g['s_tmin']), s_tmax=float(g['s_tmax']), s_noise=float(g['s_noise']))
+    sampler = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5), **kw)
+    den = DiscreteDenoiser()
+    sig = sampler.discretization(10)
+    gam = sampler._gammas(sig)
+    assert [i for i in range(10) if gam[i] > 0] == [int(i) for i in g['churned']]
+    assert [den.quantize(float(sig[i]) * (1 + gam[i]))[1] for i in range(10)] == [int(t) for t in g['idx_seen']]
+    tr = []
+    y = sampler(den.bind(m), z.clone(), cond, uc, trace=tr, step_noise=lambda i: draws[i])
+
+    class Opaque:
+        def __call__(self, input, sigma, c):
+            return den(m, input, sigma, c)
+    yg = sampler(Opaque(), z.clone(), cond, uc, step_noise=lambda i: draws[i])
+    e, em, eg = rel_l2(y.cpu(), g['final']), rel_l2(tr[5].cpu(), g['mid']), rel_l2(yg.cpu(), g['final'])
+    print('edm churn: fast', e, 'mid', em, 'generic', eg)
+    assert e < 1e-2 and em < 1e-2 and eg < 1e-2
+    assert rel_l2(yg, y) < 1e-4
+    y0 = EulerEDMSampler(num_steps=10, guider=VanillaCFG(6.5))(den.bind(m), z.clone(), cond, uc)
+    assert rel_l2(y, y0) > 1e-2                                      # the injection is not a no-op
+
+
 def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
     """BASELINE config 1: DiT-B/2, SpacedDiffusion('50').p_sample_loop, B=1 - the reference's CPU-runnable case."""
     from ln3diff_amd.dit.dit_trilatent import DiT_models
