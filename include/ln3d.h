@@ -30,8 +30,8 @@ int ln3d_abi_version(void);
 void ln3d_reload_env(void);
 
 /* Compute units of the current device (the tile selection of the GEMM / attention launchers counts them).  ABI 9 also had
- * ln3d_stream_create_cu_mask / ln3d_stream_cu_count (streams restricted to a subset of the CUs, for an experiment that measured
- * neutral: profiles/r5_lanes.md); removed in ABI 10. */
+ * two entry points for streams restricted to a subset of the CUs (create-with-CU-mask, CU count of a stream), for an experiment that
+ * measured neutral: profiles/r5_lanes.md; removed in ABI 10. */
 int ln3d_device_cus(void);
 /* Diagnostic (ABI 10): a pure-MFMA stream (wgs workgroups x 8 waves x iters x 8 v_mfma_f32_32x32x16_bf16, no memory traffic) whose timing
  * gives the matrix rate this box SUSTAINS under its power management - bench.py prints it beside the datasheet peak.  out: wgs * 512 floats.
