@@ -496,12 +496,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="t23d", choices=["t23d", "i23d"],
-                    help="t23d = BASELINE configs[1] (the metric's config); i23d = configs[2]")
+    ap.add_argument("--workload", default="t23d", choices=["t23d", "i23d", "unet"],
+                    help="t23d = BASELINE configs[1] (the metric's config); i23d = configs[2]; unet = the ShapeNet launcher's U-Net denoiser "
+                         "(sample_shapenet_car_t23d.sh: ddim250, v-prediction + mixed prediction, no CFG, batch 4) - not a BASELINE config")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (t23d: 8, i23d: 32)")
     ap.add_argument("--sample-steps", type=int, default=None, help="t23d: 250 EulerEDM steps; i23d: num_steps 50 = 49 Euler steps")
     ap.add_argument("--views", type=int, default=None, help="cameras per sample: 40 (T23D video, train_util_diffusion.py:289) / 24 (I23D, flow_matching_trainer.py:637)")
-    ap.add_argument("--res", type=int, default=256, help="render resolution (the metric: 256^2)")
+    ap.add_argument("--res", type=int, default=None, help="render resolution (the metric: 256^2; unet: the launcher's 128)")
     ap.add_argument("--arch", default=None)
     ap.add_argument("--dec-arch", default="DiT2-L/2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -516,10 +517,14 @@ def main():
                     help="go through torch.distributed.run + an RCCL process group even with --gpus 1 (the N-GPU code path on one GPU)")
     args = ap.parse_args()
     i23d = args.workload == "i23d"
-    args.batch = args.batch or (32 if i23d else 8)
+    unet = args.workload == "unet"
+    args.batch = args.batch or (4 if unet else 32 if i23d else 8)
     args.sample_steps = args.sample_steps or (50 if i23d else 250)
-    args.views = args.views or (24 if i23d else 40)
-    args.arch = args.arch or ("DiT-PixArt-L/2" if i23d else "DiT-L/2")
+    args.views = args.views or (24 if (i23d or unet) else 40)
+    args.res = args.res or (128 if unet else 256)
+    args.arch = args.arch or ("UNet-ShapeNet(320ch, attn 4,2,1)" if unet else "DiT-PixArt-L/2" if i23d else "DiT-L/2")
+    if unet and args.dec_arch == "DiT2-L/2":
+        args.dec_arch = "DiT2-B/2"                   # the second entry point's default decoder
 
     if (args.gpus > 1 or args.dist) and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -538,7 +543,18 @@ def main():
     torch.cuda.set_device(dev)
 
     # rank 0 creates the weights, every rank receives them by ONE flat RCCL broadcast per dtype
-    if i23d:
+    if unet:
+        from ln3diff_amd.guided_diffusion.unet import create_unet
+        from ln3diff_amd.synth import fill_module_random_
+        _, dec = build_models(dev, "DiT-B/2", args.dec_arch, fill=(rank == 0))
+        # DDPM_MODEL_FLAGS / DIFFUSION_FLAGS of shell_scripts/final_release/inference/sample_shapenet_car_t23d.sh (826.7 M parameters)
+        dit = create_unet(32, 320, 2, channel_mult='', learn_sigma=False, attention_resolutions='4,2,1', num_heads=8, num_head_channels=-1,
+                          num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0, denoise_in_channels=12, denoise_out_channels=12,
+                          mixed_prediction=True, use_spatial_transformer=True, transformer_depth=1, context_dim=768, mixing_logit_init=-6.0,
+                          roll_out=False).to(dev)
+        if rank == 0:
+            fill_module_random_(dit, 0, dev)
+    elif i23d:
         _, dec = build_models(dev, "DiT-B/2", args.dec_arch, fill=(rank == 0))
         dit = build_i23d(dev, args.arch, fill=(rank == 0), golden_weights=True)
     else:
@@ -562,7 +578,21 @@ def main():
     z_all[0] = synth_input('z', (1, 12, 32, 32), gseed)[0].to(dev)
     lo, hi = parallel.shard_range(Bt, rank, world)
     cams = orbit_cameras(args.views).to(dev)
-    if i23d:
+    if unet:
+        from ln3diff_amd.guided_diffusion import gaussian_diffusion as gd
+        from ln3diff_amd.guided_diffusion.respace import SpacedDiffusion, space_timesteps
+        from ln3diff_amd.pipeline import GuidedDiffusionEngine
+        diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, 'ddim%d' % args.sample_steps), betas=gd.get_named_beta_schedule('linear', 1000),
+                               model_mean_type=gd.ModelMeanType.V)
+        eng = GuidedDiffusionEngine(dit, dec, diff, triplane_scaling_divider=1.0, img_size=args.res, diffusion_input_size=32)
+        c_all = torch.randn(Bt, 77, 768, device=dev, generator=g)
+        cond = {'crossattn': c_all[lo:hi].contiguous()}
+
+        def sample_fn(lo_, hi_):
+            if hi_ <= lo_:
+                return torch.empty(0, 12, 32, 32, device=dev)
+            return eng.sample(cond, batch_size=hi_ - lo_, use_ddim=True, noise=z_all[lo_:hi_].clone(), clip_denoised=False, unconditional_guidance_scale=1.0)
+    elif i23d:
         eng = FlowMatchingEngine(dit, dec, sampling_method=args.ode_method)     # configs[2]: euler, 50 fixed steps
         c_all = {'crossattn': torch.randn(Bt, 256, 2048, device=dev, generator=g), 'vector': torch.randn(Bt, 768, device=dev, generator=g)}
         c_all['crossattn'][0] = synth_input('ca', (1, 256, 2048), gseed)[0].to(dev)
@@ -599,6 +629,8 @@ def main():
         out = one_step()
     # dominant-kernel timing INSIDE the timed region: HIP events on the launch stream around the MLP fc1 GEMM of the middle
     # layer, every denoise step (an event pair costs ~1 us of stream time per 12 ms step)
+    if unet:
+        args.no_probes, args.unfolded_steps, args.no_cpu_baseline = True, 0, True     # the DiT probes / CFG fold / oracle baseline do not apply
     if rank == 0 and not args.no_probes:
         dit._fc1_probe = {'layer': dit.depth // 2, 'events': [], 'max': 4096}
     clk = ClockSampler() if (rank == 0 and not args.no_probes) else None
@@ -642,7 +674,12 @@ def main():
     out = out_timed
 
     if rank == 0:
-        if i23d:
+        if unet:
+            wl = ("ShapeNet launcher (sample_shapenet_car_t23d.sh), NOT a BASELINE config: U-Net denoiser (320 channels, attention at 32^2 / 16^2 / 8^2, "
+                  "spatial transformer depth 1, 826.7 M parameters), DDIM %d steps, v-prediction + mixed prediction, no CFG, batch %d per GPU, VAE decode "
+                  "%s + conv decoder (the Objaverse decoder class), %d views @ %d^2" % (args.sample_steps, B, args.dec_arch, args.views, args.res))
+            metric = "3D samples/sec (ShapeNet U-Net denoiser, ddim250 + triplane decode + 128^2 render)"
+        elif i23d:
             evals = ("= %d network evaluations per sample" % (args.sample_steps - 1) if args.ode_method == "euler" else
                      "= %d per sample" % (2 * (args.sample_steps - 1)) if args.ode_method == "heun" else "network evaluations decided by the solver: see 'ode'")
             wl = ("BASELINE configs[2]: %s image-cond I23D, flow-matching ODE %s num_steps %d (%s, each on the CFG-doubled batch), CFG 4.0, "
@@ -654,7 +691,8 @@ def main():
                   "per GPU, VAE decode %s + conv decoder, %d views @ %d^2 (64+64 samples/ray)"
                   % (args.arch, args.sample_steps, B, args.dec_arch, args.views, args.res))
             metric = "3D samples/sec (250-step DiT-L/2 + 256^2 triplane render)"
-        ref_cfg = dict(arch="DiT-PixArt-L/2", sample_steps=50, batch=32, views=24, res=256, ode_method="euler") if i23d else \
+        ref_cfg = dict(workload="t23d|i23d") if unet else \
+            dict(arch="DiT-PixArt-L/2", sample_steps=50, batch=32, views=24, res=256, ode_method="euler") if i23d else \
             dict(arch="DiT-L/2", sample_steps=250, batch=8, views=40, res=256)
         dev_from = {k: getattr(args, k) for k, v in ref_cfg.items() if getattr(args, k) != v}
         if dev_from:           # a reduced / altered run must not pass for the headline configuration

@@ -459,7 +459,10 @@ __device__ __forceinline__ const char* stage_decoder(char* lds_bytes, const floa
   return cimg;
 }
 #define RENDER_LDS_BYTES (4 * WAVE_LDS_BYTES + DEC_BYTES)
-#define RENDER_K_LDS_BYTES (RENDER_WPB * WAVE_LDS_BYTES + DEC_BYTES)
+#ifndef RENDER_LDS_PAD
+#define RENDER_LDS_PAD 0        // bench builds: extra dynamic LDS per workgroup (> 80 KB leaves ONE workgroup per CU: profiles/r6_render_slp.md)
+#endif
+#define RENDER_K_LDS_BYTES (RENDER_WPB * WAVE_LDS_BYTES + DEC_BYTES + RENDER_LDS_PAD)
 
 __device__ __forceinline__ void flush_depth_range(uint32_t* scal_u, int grp, float dmin_l, float dmax_l, int lane) {
   if (grp < 0) return;

@@ -227,8 +227,9 @@ class Workspace:
 
 
 def attn_head_pad(Dh):
-    """Head size the attention kernel runs at: 64 and 128 natively, anything else (DiT-XL/2: 72) zero-padded to 128."""
-    return Dh if Dh in (64, 128) else 128
+    """Head size the attention kernel runs at: 64 and 128 natively; smaller heads (the U-Net's 32 / 40) zero-padded to 64, anything
+    between (DiT-XL/2: 72, the U-Net's 80) to 128."""
+    return 64 if Dh <= 64 else 128
 
 
 def attn_out_dim(Dh):

@@ -22,7 +22,14 @@ import torch
 import torch.nn as nn
 
 from .. import ops, _cache
-from ..dit.dit_models_xformers import Workspace, bf16, f32
+from ..dit.dit_models_xformers import Workspace, bf16, f32, pad_head_columns, self_attention_hip
+
+_MFMA_MIN_TOKENS = 256          # self-attention over at least this many tokens goes to the MFMA attention kernels (r6)
+
+
+def _mfma_head(dh):
+    """Head sizes the MFMA route takes: a multiple of 8 (the head-split GEMM epilogue) up to the attention kernels' 128."""
+    return dh % 8 == 0 and dh <= 128
 
 
 def conv_nd(dims, *a, **k):
@@ -264,6 +271,8 @@ class UNetModel(nn.Module):
                     'n1': ln(b.norm1), 'n2': ln(b.norm2), 'n3': ln(b.norm3),
                     'qkv1': _pack_lin(torch.cat([b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight], 0), None, dev),
                     'o1': _pack_lin(b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, dev),
+                    'o1p': _pack_lin(pad_head_columns(b.attn1.to_out[0].weight.detach(), m.n_heads, m.d_head), b.attn1.to_out[0].bias, dev)
+                    if _mfma_head(m.d_head) else None,
                     'q2': _pack_lin(b.attn2.to_q.weight, None, dev),
                     'kv2': _pack_lin(torch.cat([b.attn2.to_k.weight, b.attn2.to_v.weight], 0), None, dev),
                     'o2': _pack_lin(b.attn2.to_out[0].weight, b.attn2.to_out[0].bias, dev),
@@ -280,7 +289,9 @@ class UNetModel(nn.Module):
             idx = torch.arange(3 * C).reshape(nh, 3, ch).permute(1, 0, 2).reshape(-1)
             w = m.qkv.weight.detach().reshape(3 * C, C)[idx]
             return ('attention', {'n': gn(m.norm), 'qkv': _pack_lin(w, m.qkv.bias.detach()[idx], dev),
-                                  'proj': _pack_lin(m.proj_out.weight, m.proj_out.bias, dev), 'heads': nh, 'dh': ch})
+                                  'proj': _pack_lin(m.proj_out.weight, m.proj_out.bias, dev), 'heads': nh, 'dh': ch,
+                                  'projp': _pack_lin(pad_head_columns(m.proj_out.weight.detach().reshape(C, C), nh, ch), m.proj_out.bias, dev)
+                                  if _mfma_head(ch) else None})
         raise TypeError(type(m))
 
     def _ensure_packed(self, dev):
@@ -343,6 +354,13 @@ class UNetModel(nn.Module):
         self._conv3(a2, N, H, W, q['c2'], s, epi=ops.EPI_GATE_RES)
         return s
 
+    def _self_attend_mfma(self, a_bf, qkv, B, N, heads, dh):
+        """r6: self-attention over >= 256 tokens on the MFMA attention kernels (csrc/attention.hip) - the fused q|k|v GEMM splits heads in its
+        epilogue (q / k [B, H, N, Dp], V^T [B, H, Dp, N], head size zero-padded to 64 / 128: exact, the pad contributes 0 to q.k and meets zero
+        columns of the padded output projection) instead of ln3d_attention_small's one-wavefront-per-query scalar loop (1.3 GFLOP per
+        attention at the ShapeNet U-Net's 32 x 32 level).  Reference: guided_diffusion/unet.py:281-389, ldm/modules/attention_compat.py:161-277."""
+        return self_attention_hip(self._ws, 'u%d_' % dh, a_bf, B, N, heads * dh, heads, qkv['w'], qkv['b'])
+
     def _attend(self, qv, kv, vv, B, heads, Nq, Nk, dh, ldq, ldkv):
         o = self._new(B * Nq, heads * dh, torch.bfloat16)
         ops.attention_small(qv, kv, vv, o, B, heads, Nq, Nk, dh, ldq, ldkv, ldkv, dh ** -0.5)
@@ -361,10 +379,14 @@ class UNetModel(nn.Module):
                 y = self._new(rows, inner, torch.bfloat16)
                 ops.norm_modulate(tok, y, rows, inner, kind=0, eps=nw[2], shift=nw[1], scale=nw[0], mod_rows=rows, mod_ld=0)
                 return y
-            qkv = self._new(rows, 3 * inner, torch.bfloat16)
-            ops.gemm(ln(b['n1']), b['qkv1']['w'], None, ops.EPI_BF16, qkv)
-            o = self._attend(qkv, qkv[:, inner:], qkv[:, 2 * inner:], N, heads, HW, HW, dh, 3 * inner, 3 * inner)
-            ops.gemm(o, b['o1']['w'], b['o1']['b'], ops.EPI_GATE_RES, tok)
+            if b['o1p'] is not None and HW >= _MFMA_MIN_TOKENS and HW % 32 == 0:
+                o = self._self_attend_mfma(ln(b['n1']), b['qkv1'], N, HW, heads, dh)
+                ops.gemm(o, b['o1p']['w'], b['o1p']['b'], ops.EPI_GATE_RES, tok)
+            else:
+                qkv = self._new(rows, 3 * inner, torch.bfloat16)
+                ops.gemm(ln(b['n1']), b['qkv1']['w'], None, ops.EPI_BF16, qkv)
+                o = self._attend(qkv, qkv[:, inner:], qkv[:, 2 * inner:], N, heads, HW, HW, dh, 3 * inner, 3 * inner)
+                ops.gemm(o, b['o1']['w'], b['o1']['b'], ops.EPI_GATE_RES, tok)
             q2 = self._new(rows, inner, torch.bfloat16)
             ops.gemm(ln(b['n2']), b['q2']['w'], None, ops.EPI_BF16, q2)
             if ctx_bf is None:                        # no context: cross-attention defaults to self-attention (attention_compat.py:183)
@@ -385,10 +407,14 @@ class UNetModel(nn.Module):
     def _attention(self, h, q, N, H, W):
         HW, C = H * W, h.shape[1]
         a = self._gn(h, q['n'], N, HW, C, False)
+        s = h.clone()
+        if q['projp'] is not None and HW >= _MFMA_MIN_TOKENS and HW % 32 == 0:
+            o = self._self_attend_mfma(a, q['qkv'], N, HW, q['heads'], q['dh'])
+            ops.gemm(o, q['projp']['w'], q['projp']['b'], ops.EPI_GATE_RES, s)
+            return s
         qkv = self._new(N * HW, 3 * C, torch.bfloat16)
         ops.gemm(a, q['qkv']['w'], q['qkv']['b'], ops.EPI_BF16, qkv)
         o = self._attend(qkv, qkv[:, C:], qkv[:, 2 * C:], N, q['heads'], HW, HW, q['dh'], 3 * C, 3 * C)
-        s = h.clone()
         ops.gemm(o, q['proj']['w'], q['proj']['b'], ops.EPI_GATE_RES, s)
         return s
 
