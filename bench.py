@@ -28,19 +28,19 @@ def _sha16(rel):
 
 
 def pmc_traffic(key):
-    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r5_pmc.json:
+    """HBM / fabric bytes per launch of a kernel at a shape, from the committed rocprofv3 --pmc passes (profiles/r6_pmc.json:
     FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes; bench.py cannot run the profiler on itself).  An entry is
     only valid for the kernel source it was measured on: it carries the sha256 of the .hip file, and a different source on disk
     yields null plus the reason instead of a stale number."""
-    path = os.path.join(ROOT, 'profiles', 'r5_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r6_pmc.json')
     if not os.path.exists(path):
-        return None, 'profiles/r5_pmc.json missing'
+        return None, 'profiles/r6_pmc.json missing'
     ent = json.load(open(path)).get(key)
     if ent is None:
-        return None, 'no PMC entry for %s in profiles/r5_pmc.json' % key
+        return None, 'no PMC entry for %s in profiles/r6_pmc.json' % key
     cur = _sha16(ent['hip'])
     if cur != ent['sha16']:
-        return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/r5_pmc.sh' % (ent['hip'], cur, ent['sha16'])
+        return None, '%s changed since the PMC pass (sha %s, measured on %s): re-run tools/r6_pmc.sh' % (ent['hip'], cur, ent['sha16'])
     return ent['traffic_bytes'], ent['source']
 
 
@@ -267,8 +267,8 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
 
 
 def pmc_entry(key):
-    """The whole committed PMC record of a kernel (profiles/r5_pmc.json), or None when absent / measured on another source."""
-    path = os.path.join(ROOT, 'profiles', 'r5_pmc.json')
+    """The whole committed PMC record of a kernel (profiles/r6_pmc.json), or None when absent / measured on another source."""
+    path = os.path.join(ROOT, 'profiles', 'r6_pmc.json')
     if not os.path.exists(path):
         return None
     ent = json.load(open(path)).get(key)
@@ -280,7 +280,7 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
     256^2 view against 12.9 GB of gathered texel bytes), so SURVEY 8d's "gather bytes / HBM peak" is not a roofline for it (r1 - r4
     printed that ratio as frac = 2.2).  What bounds it is vector-instruction issue: `bound` = "valu-issue", `frac` = the SIMDs'
     VALU-busy cycles / elapsed cycles from the committed counter pass (SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs),
-    profiles/r5_pmc.json, tools/r5_pmc.sh), `achieved` / `peak` = vector instructions per second issued / issuable (1024 SIMDs x
+    profiles/r6_pmc.json, tools/r6_pmc.sh), `achieved` / `peak` = vector instructions per second issued / issuable (1024 SIMDs x
     clock / 4 cycles per wave64 instruction at the measured clock).  The texel-gather rate is kept as l2_gather_GBps."""
     from ln3diff_amd.synth import orbit_cameras
     tp = dec.triplane_decoder
@@ -311,10 +311,10 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
         rec.update({"achieved": round(iss["valu_insts"] / (ms * 1e-3) / 1e9, 1), "peak": round(1024 * clock_ghz / 4, 1),
                     "frac": round(iss["valu_busy_frac"], 4), "valu_insts_per_ray": round(iss["valu_insts"] / (V * res * res), 0),
                     "mfma_busy_frac": round(iss["mfma_busy_frac"], 4), "lds_busy_frac": round(iss["lds_busy_frac"], 4),
-                    "issue_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (tools/r5_pmc.sh; "
+                    "issue_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (tools/r6_pmc.sh; "
                                     "quad-cycle counters x 4, 1024 SIMDs); frac = VALU-busy SIMD cycles / elapsed SIMD cycles"})
     else:
-        rec.update({"achieved": None, "peak": None, "frac": None, "issue_source": "no counter pass for this source (profiles/r5_pmc.json): tools/r5_pmc.sh"})
+        rec.update({"achieved": None, "peak": None, "frac": None, "issue_source": "no counter pass for this source (profiles/r6_pmc.json): tools/r6_pmc.sh"})
     return rec
 
 
