@@ -86,6 +86,8 @@ class GaussianDiffusion:
         generic = not hasattr(net, 'prepare_context')           # the U-Net: no per-prompt context cache, v-prediction / mixing handled here
         assert generic or (not mixing_normal and self.model_mean_type == ModelMeanType.EPSILON), \
             "mixing_normal / v-prediction belong to the U-Net denoiser (the reference's DiT classes define no mixing_logit)"
+        if generic and isinstance(cond, dict):       # the same normalisation as ddim_sample_loop: {'c_crossattn': t} / {'crossattn': t} / tensor / None
+            cond = cond.get('c_crossattn', cond.get('crossattn'))
         if not generic and cond is not None:
             cache = net.prepare_context(cond.to(dev) if torch.is_tensor(cond) else cond)
         t_dev = torch.empty(B, device=dev, dtype=torch.float32)

@@ -175,6 +175,18 @@ class UNetModel(nn.Module):
         self.roll_out = roll_out
         if context_dim == -1:
             context_dim = None
+        # shape limits of the kernels this module launches, checked here with the reason instead of surfacing as LN3D_ERR_BAD_ARG from the
+        # first failing launch: GEMM K % 64 (every conv is an im2col GEMM with K = 9 C padded to 64, so C % 8), GroupNorm(32)
+        # groups; where a level attends: LayerNorm width % 128 and <= 1536 (ln3d_norm_modulate, checked in attn() below)
+        widths = sorted({int(model_channels * m) for m in channel_mult})
+        for w in widths:
+            if w % 32 or w % 8:
+                raise ValueError(f"UNetModel: channel width {w} (model_channels x channel_mult) must be a multiple of 32 (GroupNorm32, 8-channel im2col)")
+        if model_channels % 64:
+            raise ValueError(f"UNetModel: model_channels {model_channels} must be a multiple of 64 (time-embedding GEMM K)")
+        if context_dim not in (None, -1) and context_dim % 64:
+            raise ValueError(f"UNetModel: context_dim {context_dim} must be a multiple of 64 (GEMM K)")
+        self.use_spatial_transformer, self.context_dim = bool(use_spatial_transformer), context_dim
         if use_spatial_transformer:
             assert context_dim is not None, "use_spatial_transformer needs context_dim"
         if context_dim is not None:
@@ -194,6 +206,8 @@ class UNetModel(nn.Module):
 
         def attn(ch, heads_arg):
             nonlocal num_heads
+            if use_spatial_transformer and (ch % 128 or ch > 1536):
+                raise ValueError(f"UNetModel: a transformer at width {ch} - the LayerNorm kernel takes multiples of 128 up to 1536")
             if num_head_channels == -1:
                 dim_head = ch // num_heads
             else:
@@ -443,11 +457,16 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, get_attr='', **kwargs):
-        if isinstance(context, dict):
-            context = context['crossattn']             # sgm conditioner compat (unet.py:762-763)
+        if isinstance(context, dict):                  # sgm conditioner compat (unet.py:762-763); the guided_diffusion loops' {'c_crossattn': ..}
+            context = context['crossattn'] if 'crossattn' in context else context.get('c_crossattn')
         if get_attr != '':
             return getattr(self, get_attr)
         assert y is None, "the model is not class-conditional"
+        if self.use_spatial_transformer and context is None:
+            raise ValueError("UNetModel(use_spatial_transformer=True) needs a context [B, L, %s] (cross-attention without one is not built; "
+                             "the reference's attn2 would fall back to self-attention)" % self.context_dim)
+        if context is not None and self.use_spatial_transformer and (context.dim() != 3 or context.shape[-1] != self.context_dim or context.shape[0] != x.shape[0]):
+            raise ValueError("context %s: expected [%d, L, %d]" % (tuple(context.shape), x.shape[0], self.context_dim))
         if not x.is_cuda:
             raise RuntimeError("ln3diff_amd.UNetModel runs on the HIP device only (no CPU fallback)")
         dev = x.device
