@@ -196,7 +196,7 @@ def roofline_probe(dev, n_net, D, iters=20, tokens=768):
     peak = 2500.0   # TFLOP/s dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic("gemm_fc1_gelu_%dx%dx%d" % (M, N, K))
-    return {"kernel": "gemm_bf16_ring64_kernel<GELU_ERF, 256x256> (DiT MLP fc1)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
+    return {"kernel": "gemm_bf16_p4_kernel<GELU_ERF> (DiT MLP fc1: persistent 256x256 tiles, one wave per SIMD; r5: gemm_bf16_ring64_kernel<GELU_ERF, 256x256>)", "shape": [M, N, K], "bound": "mfma", "achieved": round(ach, 1),
             "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src, "avg_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops}
 

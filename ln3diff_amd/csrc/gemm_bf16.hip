@@ -570,13 +570,6 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x16 (&acc)[NI
 #ifndef LN3D_RING_PRE
 #define LN3D_RING_PRE 1     // bench builds only: 0 = no residual prefetch under the last K stage (the r4 epilogue)
 #endif
-#ifndef LN3D_RING_PRIO
-#define LN3D_RING_PRIO 0    // 4-wave tiles, two workgroups per CU: 1 = the wave in the SIMD's slot 0 issues at priority 3, its co-resident partner at 0
-                            // (the pair then reaches its epilogues apart instead of together); 2 = the partner starts LN3D_RING_DELAY 10-ns ticks late
-#endif
-#ifndef LN3D_RING_DELAY
-#define LN3D_RING_DELAY 600
-#endif
 #ifndef LN3D_RING_ABL
 #define LN3D_RING_ABL 0     // bench builds only: 1 = skip the epilogue, 2 = two K stages only, 4 = no DMA in the steady state, 8 = per-stage s_memtime stamps into out2
 #endif
@@ -626,14 +619,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NI * NJ <= 6) ? 2 : NW / 4) vo
     }
   }
   const int f0 = ft * BF, t0 = tt * BT;
-  if constexpr (LN3D_RING_PRIO != 0 && NW == 4 && NI * NJ <= 6) {
-    // HW_ID[3:0] = the wave's slot on its SIMD: the two workgroups sharing a CU hold different slots on every SIMD
-    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
-    if constexpr (LN3D_RING_PRIO == 1) { if (slot) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
-    if constexpr (LN3D_RING_PRIO == 2) {
-      if (slot) { const uint64_t ts = __builtin_amdgcn_s_memrealtime(); while (__builtin_amdgcn_s_memrealtime() - ts < (uint64_t)LN3D_RING_DELAY) __builtin_amdgcn_s_sleep(16); }
-    }
-  }
 
   // DMA instruction = 8 rows x 128 B -> 1 KB of the slot (W row groups first, then X row groups).  Every wave owns NPWW row
   // groups of the W tile and NPWX of the X tile, so the operand (and with it the wave-uniform base pointer) of instruction q is

@@ -86,6 +86,10 @@ int main(int argc, char** argv) {
       {"i23d fc1 GELU M49152", 49152, 4096, 1024, LN3D_EPI_GELU_ERF, 768, nullptr},
       {"small 512x512x256 plain x16", 512, 512, 256, LN3D_EPI_BF16, 512, "x16"},
       {"odd tiles 1280x768x384 plain x16", 1280, 768, 384, LN3D_EPI_BF16, 1280, "x16"},
+      {"xl2 fc1 GELU 12288x4608x1152", 12288, 4608, 1152, LN3D_EPI_GELU_ERF, 768, nullptr},
+      {"xl2 fc1 GELU 12288x4608x1152 x16", 12288, 4608, 1152, LN3D_EPI_GELU_ERF, 768, "x16"},
+      {"dit2 fc1 GELU 24576x4096x1024", 24576, 4096, 1024, LN3D_EPI_GELU_ERF, 3072, nullptr},
+      {"dit2 fc1 GELU 24576x4096x1024 x7", 24576, 4096, 1024, LN3D_EPI_GELU_ERF, 3072, "x7"},
       {"fc1 GELU x13 (256x256, 4 waves)", 12288, 4096, 1024, LN3D_EPI_GELU_ERF, 768, "x13"},
       {"fc1 plain x13", 12288, 4096, 1024, LN3D_EPI_BF16, 768, "x13"},
       {"qkv plain x13", 12288, 3072, 1024, LN3D_EPI_BF16, 768, "x13"},
