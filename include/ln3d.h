@@ -276,7 +276,7 @@ typedef struct {
    * and the depth clamp to [min, max] of all sample depths (ray_marcher.py:57-61).  views_per_call = how many consecutive views
    * form one such call: 0 (or >= V) = the whole launch is one call (Triplane.forward on a batch); 1 = every view is its own
    * call (the video drivers render one camera per call, nsr/train_util_diffusion.py:262-283).  At most
-   * (LN3D_RENDER_SCRATCH_FLOATS - 2400) / 8 calls per launch. */
+   * (LN3D_RENDER_SCRATCH_FLOATS - 2656) / 8 calls per launch. */
   int views_per_call;
   /* ---- ABI 9.  All zero = the behaviour of ABI 8 (Objaverse preset, res x res rays per view). */
   int rays_per_view;     /* M of an explicit ray list [V, M, 3] (any M >= 1, the seam's [N, M, 3] rays are not an image); 0 = res * res.

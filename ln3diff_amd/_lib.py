@@ -22,7 +22,7 @@ SYMBOLS = [
 
 EPI_F32, EPI_BF16, EPI_GELU_ERF, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RES, EPI_HEADS, EPI_F32_SILU, EPI_QUICK_GELU, EPI_CROSS_ATTN = range(10)
 RENDER_SCRATCH_FLOATS = 16384
-RENDER_MAX_CALLS = (RENDER_SCRATCH_FLOATS - 2392) // 8      # per-call range records after the decoder image (csrc/render.hip)
+RENDER_MAX_CALLS = (RENDER_SCRATCH_FLOATS - 2644) // 8      # per-call range records after the decoder image (csrc/render.hip)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 

@@ -31,14 +31,14 @@
 // scalars[]: [0..15] unused, then the decoder image that every workgroup copies into its LDS:
 //   A1  : 8 fragments (split s, hidden tile jt, k-step ks) x 64 lanes x 16 B           at DEC_A1  (8 KB)
 //   A2  : rows 0-3 only: [split s][k-step s2][hi][output o] x 16 B (other rows are zero)  at DEC_A2  (1 KB)
-//   Z   : 16 zero bytes (the A2 fragment of the lanes whose row is >= 4)                  at DEC_Z
+//   Z   : 1 KB of zeros (the A2 fragments of the lanes whose row is >= 4, same immediates)  at DEC_Z
 //   B0  : hidden bias as C fragments [jt][hi][16] f32 (pre-multiplied by log2 e)         at DEC_B0  (256 B)
 //   B1  : output bias [4] f32                                                            at DEC_B1  (16 B)
 #define DEC_OFF 16
 #define DEC_A1 0
 #define DEC_A2 8192
 #define DEC_Z (8192 + 1024)
-#define DEC_B0 (8192 + 1024 + 16)
+#define DEC_B0 (8192 + 1024 + 1024)
 #define DEC_B1 (DEC_B0 + 256)
 #define DEC_BYTES (DEC_B1 + 16)
 #define DEC_FLOATS (DEC_BYTES / 4)
@@ -174,7 +174,7 @@ __global__ void render_init_kernel(uint32_t* scal_u, int groups, float* dec, con
     split_bf16(w1[o * 64 + hid] * g1, h, l);
     reinterpret_cast<bf16_t*>(img + DEC_A2)[i] = sp ? l : h;
   }
-  for (int i = t; i < 4; i += nt) reinterpret_cast<uint32_t*>(img + DEC_Z)[i] = 0u;
+  for (int i = t; i < 256; i += nt) reinterpret_cast<uint32_t*>(img + DEC_Z)[i] = 0u;
   for (int i = t; i < 2 * 2 * 16; i += nt) {
     const int r = i & 15, hi = (i >> 4) & 1, jt = i >> 5;
     reinterpret_cast<float*>(img + DEC_B0)[i] = b0[jt * 32 + acc_row(r, hi)] * 1.4426950408889634f;
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256) void ray_limits_kernel(RenderP p, float box_ha
 typedef __attribute__((address_space(3))) const bf16x8 lds_bfrag_t;
 __device__ __forceinline__ float softplus_log2(float x) {   // log2(1 + 2^x); x carries log2(e), the caller's next layer ln(2)
   const float y = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(x));
-  return x > 28.853900817779268f ? x : y;                     // torch softplus threshold 20, in log2 units
+  // torch's threshold (x > 20 -> x) is only NEEDED where 2^x overflows: below it y >= x holds to the last ulp or two and for
+  // x >= 25 fl(1 + 2^x) = 2^x, so y is x already.  median(y, x, 128) = y while x <= y <= 128 and x once y = +inf: one instruction
+  // instead of a compare + select, 128 times per ray (r6)
+  return __builtin_amdgcn_fmed3f(y, x, 128.0f);
 }
 
 // torch softplus (beta 1, threshold 20) and exp(-t) of the ray-marcher on the transcendental unit (r4).  The libm forms
@@ -236,6 +239,12 @@ __device__ __forceinline__ float softplus20_hw(float x) {
   return x > 20.0f ? x : fmaxf(x, 0.f) + l1p;
 }
 __device__ __forceinline__ float exp_neg_hw(float t) { return __builtin_amdgcn_exp2f(t * -1.4426950408889634f); }   // exp(-t)
+
+__device__ __forceinline__ float even_reg(float x) {
+  float r;
+  asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 __device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, char* wl, const char* cimg,
                                         float px, float py, float pz, int lane, float rgb[3], float& sigma) {
@@ -279,19 +288,66 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     toff[4 * pl + 0] = (pb + (yc0 * p.W + xc0) * 32) * 4; toff[4 * pl + 1] = (pb + (yc0 * p.W + xc1) * 32) * 4;
     toff[4 * pl + 2] = (pb + (yc1 * p.W + xc0) * 32) * 4; toff[4 * pl + 3] = (pb + (yc1 * p.W + xc1) * 32) * 4;
   }
-  const char* pbase = reinterpret_cast<const char*>(planes) + c4 * 16;
-  auto fetch = [&](int it, float4 (&t)[12], float (&a)[12]) {
-    const int bsel = (it * 8 + g) << 2;                   // ds_bpermute byte address of the owner lane
+  // ---- r6: the setup hand-off goes through the wave's feature tile instead of 24 ds_bpermute per 8-point iteration.  Row s of the tile
+  // (128 B, free until the features of point s land in it - in the very iteration that consumes its setup, behind the reads: a
+  // wave's LDS operations execute in program order) takes point s's 12 tap offsets + 12 tap weights as six 16-byte chunks, chunk c at
+  // position c ^ (s & 7): the 8 rows a gather iteration reads (one per lane group g, every lane of the group the same address =
+  // broadcast) sit in 8 different chunk positions, so both the b128 writes and the b128 reads are conflict-free.  6 + 8 x 6 LDS
+  // instructions per pass instead of 8 x 24, and the 24 setup registers are not live across the loop any more - which is what makes
+  // room for the decoder's accumulators beside the gather (below).
+  const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)wl;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) i32x4 lds_i4;
+  typedef __attribute__((address_space(3))) f32x4 lds_f4;
+  {
+    lds_i4* const row = reinterpret_cast<lds_i4*>((uintptr_t)wb) + lane * 8;       // 16-byte chunk units
+    const int k7 = lane & 7;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      row[c ^ k7] = i32x4{toff[4 * c], toff[4 * c + 1], toff[4 * c + 2], toff[4 * c + 3]};
+      reinterpret_cast<lds_f4*>(row)[(3 + c) ^ k7] = f32x4{tw[4 * c], tw[4 * c + 1], tw[4 * c + 2], tw[4 * c + 3]};
+    }
+  }
+  wave_sync();
+  // the plane base as a scalar pair + a 32-bit per-lane byte offset: global_load_dwordx4 v, v_off, s[base] (no 64-bit address arithmetic
+  // per tap: it was 24 of the ~90 vector instructions of an iteration).  planes is wave-uniform (one ray = one wave).
+  typedef __attribute__((address_space(1))) const char gchar_t;
+  const uint64_t pl64 = reinterpret_cast<uint64_t>(planes);
+  gchar_t* const pbase = reinterpret_cast<gchar_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pl64 >> 32)) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pl64));
+  const uint32_t c4b = c4 * 16;
+  const lds_i4* const srow = reinterpret_cast<const lds_i4*>((uintptr_t)wb) + g * 8;      // this lane group's setup row of iteration 0
+  auto fetch = [&](int it, float4 (&t)[12]) {
+    int off[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const i32x4 o4 = srow[it * 64 + (c ^ g)];
+      off[4 * c] = o4.x; off[4 * c + 1] = o4.y; off[4 * c + 2] = o4.z; off[4 * c + 3] = o4.w;
+    }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-      const int off = __builtin_amdgcn_ds_bpermute(bsel, toff[k]);
-      a[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsel, __float_as_int(tw[k])));
-      if constexpr (!(LN3D_RENDER_ABL & 2)) t[k] = *reinterpret_cast<const float4*>(pbase + off);
-      else t[k] = make_float4(a[k], (float)off, 1.f, 2.f);
+      if constexpr (!(LN3D_RENDER_ABL & 2))
+      {
+        const f32x4 tv = *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>(pbase + ((uint32_t)off[k] + c4b));
+        t[k] = make_float4(tv.x, tv.y, tv.z, tv.w);
+      }
+      else t[k] = make_float4((float)k, (float)off[k], 1.f, 2.f);
     }
   };
-  auto reduce = [&](int it, const float4 (&t)[12], const float (&a)[12]) {
-    const int src = it * 8 + g;
+  // the tap weights are read where they are used (behind whatever was placed under the loads): 12 registers less across that code
+  char* const wrow = wl + g * 128 + (c4 & 1) * 8 + (((c4 >> 1) ^ (g >> 1)) << 4);
+  auto reduce = [&](int it, const float4 (&t)[12]) {
+    float a[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4 w4 = reinterpret_cast<const lds_f4*>(srow)[it * 64 + ((3 + c) ^ g)];
+      // .y / .w arrive in ODD registers.  Broadcasting an odd register into a packed-fp32 source needs op_sel = 1 (the low result lane
+      // reads the high half of the pair), and that form is NOT reliable on gfx950: lanes 48 - 63 come out wrong from time to time as soon
+      // as a second wave shares the SIMD (profiles/r6_render_opsel.md - the root cause of the r3 - r6 "SLP irreproducibility").  A copy
+      // into a fresh register lets hipcc place the value in the low half of a pair (op_sel_hi-only forms, like every other packed
+      // instruction of the library); tools/check_isa.py rejects a build that contains the op_sel form anywhere.
+      a[4 * c] = w4.x; a[4 * c + 1] = even_reg(w4.y); a[4 * c + 2] = w4.z; a[4 * c + 3] = even_reg(w4.w);
+    }
     // explicit packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, r3): a texel's float4 is two even-aligned register pairs and
     // the tap weight is broadcast by op_sel, so the 48 + 12 + 4 scalar operations of an iteration are 24 + 6 + 2 packed ones; per
     // channel the evaluation order is the reference's grid_sample order ((nw + ne) + sw) + se, then the plane sum, unchanged
@@ -321,91 +377,109 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     hv.x = (u0 >> 16) | u1; hv.y = (u2 >> 16) | u3;
     lv.x = pack2bf(acc.x - __uint_as_float(u0), acc.y - __uint_as_float(u1));
     lv.y = pack2bf(acc.z - __uint_as_float(u2), acc.w - __uint_as_float(u3));
-    const int key = (src >> 1) & 7;
-    char* row = wl + src * 128 + (c4 & 1) * 8;
-    *reinterpret_cast<uint2*>(row + (((c4 >> 1) ^ key) << 4)) = hv;
-    *reinterpret_cast<uint2*>(row + (((4 + (c4 >> 1)) ^ key) << 4)) = lv;
+    // key = (src >> 1) & 7 = (g >> 1) + 4 * (it & 1): the hi half sits at chunk p = (c4 >> 1) ^ (g >> 1) on even iterations and p + 4 on odd
+    // ones, the lo half at the other - ONE lane-constant address + immediates for the whole pass
+    *reinterpret_cast<uint2*>(wrow + it * 1024 + ((it & 1) ? 64 : 0)) = hv;
+    *reinterpret_cast<uint2*>(wrow + it * 1024 + ((it & 1) ? 0 : 64)) = lv;
   };
-  {
-    // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
-    // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
-    float4 tA[12];
-    float aA[12];
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-      fetch(it, tA, aA);
-      reduce(it, tA, aA);
-    }
-  }
-  wave_sync();
+  // ---- the 32 -> 64 -> 4 decoder of one 32-point tile in four pieces (hidden tile jt = 0, 1: layer 1 + softplus, then its two k-steps of
+  // layer 2), so that the pieces of point tile 0 can be placed between the load issue and the load use of gather iterations 4 - 7
   const int l31 = lane & 31, hi = lane >> 5;
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (!(LN3D_RENDER_ABL & 1)) {
-    const uint32_t cb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)cimg;
-    const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)wl;
-    const float4 b1 = *reinterpret_cast<const float4*>(cimg + DEC_B1);
-#pragma unroll 1
-    for (int pt = 0; pt < 2; ++pt) {
-      const int prow = pt * 32 + l31, key = (prow >> 1) & 7;
-      bf16x8 bh[2], bl[2];
+  const uint32_t cb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)cimg;
+  auto mlp_l1 = [&](int pt, int jt, f32x16& hacc) {
+    const int prow = pt * 32 + l31, key = (prow >> 1) & 7;
+    // hidden tile jt: 32 hidden units x the 32 points, bias as the C operand
+    const float4* bp = reinterpret_cast<const float4*>(cimg + DEC_B0 + (jt * 2 + hi) * 64);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bh[ks] = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((2 * ks + hi) ^ key) << 4));
-        bl[ks] = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((4 + 2 * ks + hi) ^ key) << 4));
-      }
-      f32x16 oacc;
+    for (int q = 0; q < 4; ++q) { const float4 b = bp[q]; hacc[4 * q] = b.x; hacc[4 * q + 1] = b.y; hacc[4 * q + 2] = b.z; hacc[4 * q + 3] = b.w; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 bh = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((2 * ks + hi) ^ key) << 4));
+      const bf16x8 bl = *(lds_bfrag_t*)(uintptr_t)(wb + prow * 128 + (((4 + 2 * ks + hi) ^ key) << 4));
+      const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((0 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
+      const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((1 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, hacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = softplus_log2(hacc[r]);
+  };
+  // layer-2 A fragment (split s, k-step s2) of lane (row l31 < 4, hi) at DEC_A2 + (s * 4 + s2) * 128 + hi * 64 + l31 * 16; the lanes of the
+  // 28 padding rows read zeros at the same immediates from DEC_Z (1 KB of zeros): one lane-constant address for all eight fragments
+  const uint32_t a2base = l31 < 4 ? cb + DEC_A2 + hi * 64 + l31 * 16 : cb + DEC_Z;
+  auto mlp_l2 = [&](int jt, const f32x16& hacc, f32x16& oacc) {
+    if (jt == 0) {                                     // the output accumulator starts here (an inline-zero C operand), not a gather iteration earlier
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        // hidden tile jt: 32 hidden units x the 32 points, bias as the C operand, then its two k-steps of layer 2
-        f32x16 hacc;
-        const float4* bp = reinterpret_cast<const float4*>(cimg + DEC_B0 + (jt * 2 + hi) * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const float4 b = bp[q]; hacc[4 * q] = b.x; hacc[4 * q + 1] = b.y; hacc[4 * q + 2] = b.z; hacc[4 * q + 3] = b.w; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((0 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
-          const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)(cb + DEC_A1 + ((1 * 2 + jt) * 2 + ks) * 1024 + lane * 16);
-          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], hacc, 0, 0, 0);
-          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], hacc, 0, 0, 0);
-          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], hacc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] = softplus_log2(hacc[r]);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-          const int s2 = 2 * jt + sh;
-          union { uint32_t u[4]; bf16x8 v; } ph, pl_;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float f0 = hacc[8 * sh + 2 * e], f1 = hacc[8 * sh + 2 * e + 1];
-            const uint32_t w0 = __float_as_uint(f0) & 0xffff0000u, w1 = __float_as_uint(f1) & 0xffff0000u;
-            ph.u[e] = (w0 >> 16) | w1;
-            pl_.u[e] = pack2bf(f0 - __uint_as_float(w0), f1 - __uint_as_float(w1));
-          }
-          const uint32_t a2h = l31 < 4 ? cb + DEC_A2 + (((0 * 4 + s2) * 2 + hi) * 4 + l31) * 16 : cb + DEC_Z;
-          const uint32_t a2l = l31 < 4 ? cb + DEC_A2 + (((1 * 4 + s2) * 2 + hi) * 4 + l31) * 16 : cb + DEC_Z;
-          const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)a2h;
-          const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)a2l;
-          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph.v, oacc, 0, 0, 0);
-          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl_.v, oacc, 0, 0, 0);
-          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph.v, oacc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);               // keep the two hidden tiles apart: one set of fragments live at a time
-      }
-      // rows 0-3 = (sigma, r, g, b) of point pt*32 + l31, in registers 0-3 of lanes 0-31
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // point tile 0 lives in the lanes that hold its results already; tile 1's results move up by 32 lanes
-        const float v = pt == 0 ? oacc[k] : __shfl(oacc[k], l31, 64);
-        if (hi == pt) o[k] = v;
-      }
     }
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+      const int s2 = 2 * jt + sh;
+      union { uint32_t u[4]; bf16x8 v; } ph, pl_;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f0 = hacc[8 * sh + 2 * e], f1 = hacc[8 * sh + 2 * e + 1];
+        const uint32_t w0 = __float_as_uint(f0) & 0xffff0000u, w1 = __float_as_uint(f1) & 0xffff0000u;
+        ph.u[e] = (w0 >> 16) | w1;
+        pl_.u[e] = pack2bf(f0 - __uint_as_float(w0), f1 - __uint_as_float(w1));
+      }
+      const bf16x8 ah = *(lds_bfrag_t*)(uintptr_t)(a2base + (0 * 4 + s2) * 128);
+      const bf16x8 al = *(lds_bfrag_t*)(uintptr_t)(a2base + (1 * 4 + s2) * 128);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph.v, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl_.v, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph.v, oacc, 0, 0, 0);
+    }
+  };
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  // rows 0-3 = (sigma, r, g, b) of point pt*32 + l31, in registers 0-3 of lanes 0-31
+  auto mlp_out = [&](int pt, const f32x16& oacc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // point tile 0 lives in the lanes that hold its results already; tile 1's results move up by 32 lanes
+      const float v = pt == 0 ? oacc[k] : __shfl(oacc[k], l31, 64);
+      if (hi == pt) o[k] = v;
+    }
+  };
+  constexpr bool kMlp = !(LN3D_RENDER_ABL & 1);
+  float4 tA[12];
+  // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
+  // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
+#ifndef LN3D_RENDER_SEQ   // bench-only: 1 = the decoder of point tile 0 behind the whole gather instead of under its second half
+#define LN3D_RENDER_SEQ 0
+#endif
+#pragma unroll 1
+  for (int it = 0; it < (LN3D_RENDER_SEQ ? 8 : 4); ++it) {
+    fetch(it, tA);
+    reduce(it, tA);
+  }
+  wave_sync();
+  // r6: points 0 - 31 are complete: their decoder runs UNDER the texel loads of points 32 - 63 (a piece per gather iteration, between
+  // the issue of the iteration's 12 loads and their first use), so half of the decoder's matrix / transcendental chain costs no
+  // time of its own.  Same arithmetic in the same order per point: bit-identical to the r5 kernel.
+  f32x16 hacc, oacc;
+#define SB0_ __builtin_amdgcn_sched_barrier(0)
+  if constexpr (LN3D_RENDER_SEQ) {
+    if constexpr (kMlp) { mlp_l1(0, 0, hacc); mlp_l2(0, hacc, oacc); SB0_; mlp_l1(0, 1, hacc); mlp_l2(1, hacc, oacc); mlp_out(0, oacc); }
+  } else {
+    fetch(4, tA); SB0_; if constexpr (kMlp) mlp_l1(0, 0, hacc); SB0_; reduce(4, tA); SB0_;
+    fetch(5, tA); SB0_; if constexpr (kMlp) mlp_l2(0, hacc, oacc); SB0_; reduce(5, tA); SB0_;
+    fetch(6, tA); SB0_; if constexpr (kMlp) mlp_l1(0, 1, hacc); SB0_; reduce(6, tA); SB0_;
+    fetch(7, tA); SB0_; if constexpr (kMlp) mlp_l2(1, hacc, oacc); SB0_; reduce(7, tA); SB0_;
+    if constexpr (kMlp) mlp_out(0, oacc);
+    wave_sync();
+  }
+  if constexpr (kMlp) {
+    mlp_l1(1, 0, hacc); mlp_l2(0, hacc, oacc);
+    SB0_;                                              // keep the two hidden tiles apart: one set of fragments live at a time
+    mlp_l1(1, 1, hacc); mlp_l2(1, hacc, oacc);
+    mlp_out(1, oacc);
+    const float4 b1 = *reinterpret_cast<const float4*>(cimg + DEC_B1);
     o[0] += b1.x; o[1] += b1.y; o[2] += b1.z; o[3] += b1.w;
   } else {
     o[0] = sx; o[1] = sy; o[2] = sz; o[3] = sx + sy;
   }
+#undef SB0_
   wave_sync();   // the wave's LDS may be overwritten by the caller / next pass
   sigma = inb ? o[0] : sg_fill;
   rgb[0] = inb ? (1.0f / (1.0f + __expf(-o[1]))) * 1.002f - 0.001f : 0.f;
