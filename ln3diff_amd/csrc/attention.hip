@@ -51,20 +51,35 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // its counted waits stay those of the DH-wide layout).
 template <int DH, int OCC, int DT = DH>
 __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
-  constexpr int NST = DH == 64 ? 4 : 3;           // ring depth
-  constexpr int KROWB = DH * 2;                   // K tile row bytes
+#ifndef LN3D_ATTN_NST128
+#define LN3D_ATTN_NST128 3       // bench-only: ring depth of the 128-wide instantiations (4 x 32 KB still fits the CU: one workgroup either way)
+#endif
+#ifndef LN3D_ATTN_PRIO
+#define LN3D_ATTN_PRIO 0         // bench-only: static priority for waves 4-7 (what attn_kres_kernel does) so that the two waves of a SIMD drift apart
+#endif
+  constexpr int NST = DH == 64 ? 4 : (DH == 80 ? 3 : LN3D_ATTN_NST128);           // ring depth
+  // DH = 80 (r6: DiT-XL/2's 72-wide and the U-Net's 80-wide heads, stored 80 wide instead of 128): the K rows (160 B) sit in LDS at a
+  // 176-byte pitch - 11 chunks, an odd count, so that the 8 rows a b128 read phase touches fall into 8 different bank groups without a
+  // swizzle (XOR needs a power-of-two row) - and the V^T tile keeps room for 96 rows (3 MFMA row blocks; rows 80 - 95 are never loaded and
+  // only feed accumulator rows that are never stored).  What the narrower storage buys is L2 / fabric traffic: the K / V^T stream of a launch
+  // (every query block re-reads its head) is what bounds this kernel at these shapes - 128-wide tiles of 72-wide heads cost 77 us whether
+  // 22 or 32 MFMAs per block run on them, with a 3- or a 4-deep ring (profiles/r6_attn.md).
+  constexpr int KROWB = DH == 80 ? 176 : DH * 2;  // K tile row pitch in LDS
   constexpr int KTILE = KVB * KROWB;
-  constexpr int VTILE = DH * 128;                 // V^T tile: DH rows x 64 keys
+  constexpr int VTILE = (DH == 80 ? 96 : DH) * 128;   // V^T tile: DH rows x 64 keys
   constexpr int STAGEB = KTILE + VTILE;
   constexpr int NDS = (DT + 15) / 16, NDT = (DT + 31) / 32;
   static_assert(DT <= DH && DT % 8 == 0, "true head size: a multiple of 8 within the stored row");
-  constexpr int LPW = DH / 64;                    // DMA instructions per wave per tile (K and V^T each)
-  constexpr int KCH = DH / 8;                     // 16-B chunks per K row (8 or 16)
+  static_assert(DH == 64 || DH == 80 || DH == 128, "stored head width");
+  constexpr int NKI = KTILE / 1024, NVI = DH * 128 / 1024;    // wave-level DMA instructions per K / V^T tile (1024 LDS bytes each)
+  constexpr int LPW = (NKI + NVI + 7) / 8;        // DMA instruction slots per wave per stage: slot s = wid + 8 i is K instruction s (s < NKI) or V^T instruction s - NKI
+  constexpr int KCH = DH / 8;                     // 16-B chunks per K row in memory (8, 10 or 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
+  if constexpr (LN3D_ATTN_PRIO != 0) { if (wid >= 4) __builtin_amdgcn_s_setprio(LN3D_ATTN_PRIO); }
   // block -> (head, query block): the query blocks of a head run on ONE XCD (block b runs on XCD b % 8), next to each other in
   // dispatch order, so that the head's K / V^T stream is fetched into that XCD's L2 once (r4; a (query block, head) grid spread
   // them over three XCDs)
@@ -88,28 +103,39 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
     for (int ds = 0; ds < NDS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
   }
 
-  // DMA source addressing: wave-instruction j of a tile writes LDS bytes [1024 j, 1024 j + 1024)
-  const bf16_t* ksrc[LPW]; const bf16_t* vsrc[LPW];
-  int kdst[LPW], vdst[LPW];
+  // DMA source addressing: wave-instruction j of a tile writes LDS bytes [1024 j, 1024 j + 1024).  A wave owns the slots wid, wid + 8, ...
+  // of the stage's NKI + NVI instructions (64 / 128 wide: one or two K and as many V^T instructions each, as before; 80 wide: 11 + 10
+  // instructions, three for waves 0 - 4 and two for waves 5 - 7 - the counted waits below use the wave's own count).
+  const bf16_t* dsrc[LPW];
+  int ddst[LPW], dstep[LPW];
+  int nslot = 0;                                   // wave-uniform: this wave's DMA instructions per stage
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    const int j = wid + 8 * i;
-    const int krow = j * (1024 / KROWB) + lane / KCH, kcp = lane % KCH;
-    const int kkey = DH == 64 ? ((krow >> 1) & 7) : (krow & 15);
-    ksrc[i] = Kg + (int64_t)krow * DH + ((kcp ^ kkey) * 8);
-    kdst[i] = j * 1024;
-    const int vrow = j * 8 + (lane >> 3), vcp = lane & 7;
-    vsrc[i] = Vg + (int64_t)vrow * p.Nk_pad + ((vcp ^ ((vrow >> 1) & 7)) * 8);
-    vdst[i] = KTILE + j * 1024;
+    const int sl = wid + 8 * i;
+    if (sl < NKI) {
+      const int j = sl;
+      int krow, kcp;
+      if constexpr (DH == 80) { const int n = j * 64 + lane; krow = n / 11; kcp = n - krow * 11; kcp = kcp < 10 ? kcp : 9; }   // pitch chunk 10 = padding: any valid address
+      else { krow = j * (1024 / KROWB) + lane / KCH; kcp = lane % KCH; }
+      const int kkey = DH == 64 ? ((krow >> 1) & 7) : (DH == 128 ? (krow & 15) : 0);
+      dsrc[i] = Kg + (int64_t)krow * DH + ((kcp ^ kkey) * 8);
+      ddst[i] = j * 1024;
+      dstep[i] = KVB * DH;
+    } else {
+      const int j = sl - NKI < NVI ? sl - NKI : NVI - 1;
+      const int vrow = j * 8 + (lane >> 3), vcp = lane & 7;
+      dsrc[i] = Vg + (int64_t)vrow * p.Nk_pad + ((vcp ^ ((vrow >> 1) & 7)) * 8);
+      ddst[i] = KTILE + j * 1024;
+      dstep[i] = KVB;
+    }
+    if (sl < NKI + NVI) nslot = i + 1;
   }
 #define A_ISSUE(kbv)                                                                                          \
   {                                                                                                           \
     const int kb_i_ = (kbv);                                                                                  \
     char* sb_ = smem + (kb_i_ % NST) * STAGEB;                                                                \
-    _Pragma("unroll") for (int ii_ = 0; ii_ < LPW; ++ii_) {                                                   \
-      lds_dma16_v((ksrc[ii_] + (int64_t)kb_i_ * KVB * DH), lds_addr((sb_ + kdst[ii_]))); \
-      lds_dma16_v((vsrc[ii_] + kb_i_ * KVB), lds_addr((sb_ + vdst[ii_]))); \
-    }                                                                                                         \
+    _Pragma("unroll") for (int ii_ = 0; ii_ < LPW; ++ii_)                                                     \
+      if (ii_ < nslot) lds_dma16_v((dsrc[ii_] + (int64_t)kb_i_ * dstep[ii_]), lds_addr((sb_ + ddst[ii_])));  \
   }
 
   f32x16 oacc[NDT];
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
   const int nkb = (p.Nk + KVB - 1) / KVB;
 
   // fragment read offsets
-  const int kkey_r = DH == 64 ? ((l31 >> 1) & 7) : (l31 & 15);      // key rows kt*32 + l31: kt*32 does not change the key
+  const int kkey_r = DH == 64 ? ((l31 >> 1) & 7) : (DH == 128 ? (l31 & 15) : 0);      // key rows kt*32 + l31: kt*32 does not change the key
   const int k_off = l31 * KROWB;
   const int vkey_r = (l31 >> 1) & 7;
   const int v_off = KTILE + l31 * 128;
@@ -211,8 +237,11 @@ __global__ __launch_bounds__(512, OCC) void attn_kernel(AttnP p) {
 #define A_WAIT(kbv)                                                                                         \
   {                                                                                                           \
     const int ahead_ = min(NST - 2, nkb - 1 - (kbv));   /* blocks that may stay in flight while block kb is consumed */ \
-    if (ahead_ >= 2) { if constexpr (LPW == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
-    else if (ahead_ == 1) { if constexpr (LPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+    const int infl_ = ahead_ * nslot;                   /* this wave's DMA instructions behind block kb's: 0, 2, 3, 4 or 6 */ \
+    if (infl_ >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
+    else if (infl_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+    else if (infl_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                   \
+    else if (infl_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_s_waitcnt(0xC07F);                 /* this wave's LDS reads of block kb-1 are complete */  \
     __builtin_amdgcn_s_barrier();                                                                             \
@@ -1256,8 +1285,8 @@ static int launch_attn_short(const AttnP& p, hipStream_t s) {
 
 template <int DH, int OCC, int DT = DH>
 static int launch_attn(const AttnP& p, hipStream_t s) {
-  constexpr int NST = DH == 64 ? 4 : 3;
-  constexpr int LDS = NST * (KVB * DH * 2 + DH * 128);
+  constexpr int NST = DH == 64 ? 4 : (DH == 80 ? 3 : LN3D_ATTN_NST128);
+  constexpr int LDS = DH == 80 ? NST * (KVB * 176 + 96 * 128) : NST * (KVB * DH * 2 + DH * 128);
   static AttrOnce attr_once;
   if (attr_once.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DH, OCC, DT>),
@@ -1312,7 +1341,7 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // causal masking exists in the short-sequence kernel only (its one user is the 77-token CLIP text tower)
   if (a->causal && !(a->Dh == 64 && a->Nk <= 128)) return LN3D_ERR_UNSUPPORTED;
-  if (a->Dh_true != 0 && a->Dh_true != a->Dh && a->Dh != 128) return LN3D_ERR_UNSUPPORTED;   // compact heads: the padded-128 kernel only
+  if (a->Dh_true != 0 && a->Dh_true != a->Dh && a->Dh != 128 && a->Dh != 80) return LN3D_ERR_UNSUPPORTED;   // compact heads: the padded kernels only
   if (a->Dh == 64) {
     // The short-sequence kernel serves the causal text tower; for the non-causal 77-key cross-attention it measures 2 us
     // faster in isolation but slower inside the sampling loop than the ring kernel (and the DiT runs that attention inside
@@ -1327,6 +1356,11 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
     }
     return a->Nk > 128 ? launch_attn<64, 4>(p, s) : launch_attn<64, 2>(p, s);
   }
+  if (a->Dh == 80) {                                                        // r6: 65 - 80 wide heads stored 80 wide
+    if (a->Dh_true == 0 || a->Dh_true == 80) return launch_attn<80, 2>(p, s);   // the U-Net's 80-wide heads
+    if (a->Dh_true == 72) return launch_attn<80, 2, 72>(p, s);                // DiT-XL/2
+    return LN3D_ERR_UNSUPPORTED;
+  }
   if (a->Dh == 128) {
     if (a->Dh_true == 0 || a->Dh_true == 128) return launch_attn<128, 2>(p, s);
     if (a->Dh_true == 72) return launch_attn<128, 2, 72>(p, s);           // DiT-XL/2
@@ -1338,16 +1372,18 @@ extern "C" int ln3d_attention_bf16(const ln3d_attn_args* a, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // per-head RMSNorm on q / k (qk_norm): rows of Dh bf16, in place; one 16-lane group per row (Dh=64)
 __global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, int Dh, int true_dim, float eps) {
-  const int per = Dh / 4;                          // lanes per row, 4 elements each
+  const int per = Dh <= 64 ? 16 : 32;              // lanes per row (a power of two for the butterfly), 4 elements each; lanes beyond Dh / 4 idle
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / per;
   const int c = (int)(gid % per);
-  if (row >= rows) return;
-  bf16_t* px = x + row * Dh + c * 4;
-  const uint2 raw = *reinterpret_cast<const uint2*>(px);
+  const bool act = row < rows && c * 4 < Dh;
+  bf16_t* px = x + (act ? row * Dh + c * 4 : 0);
+  uint2 raw = make_uint2(0u, 0u);
+  if (act) raw = *reinterpret_cast<const uint2*>(px);
   float v0 = bf2f(raw.x & 0xffff), v1 = bf2f(raw.x >> 16), v2 = bf2f(raw.y & 0xffff), v3 = bf2f(raw.y >> 16);
   float ss = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
   for (int o = per >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (!act) return;
   const float rs = rsqrtf(ss / true_dim + eps);
   const float4 ww = *reinterpret_cast<const float4*>(w + c * 4);
   uint2 o;
@@ -1357,9 +1393,9 @@ __global__ void rmsnorm_heads_kernel(bf16_t* x, const float* w, int64_t rows, in
 }
 
 extern "C" int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, int true_dim, float eps, void* stream) {
-  if (!x || !w || (Dh != 64 && Dh != 128) || true_dim < 0 || true_dim > Dh) return LN3D_ERR_BAD_ARG;
+  if (!x || !w || (Dh != 64 && Dh != 80 && Dh != 128) || true_dim < 0 || true_dim > Dh) return LN3D_ERR_BAD_ARG;
   if (true_dim == 0) true_dim = Dh;
-  const int per = Dh / 4;
+  const int per = Dh <= 64 ? 16 : 32;
   const int64_t threads = rows * per;
   hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)x, w, rows, Dh, true_dim, eps);

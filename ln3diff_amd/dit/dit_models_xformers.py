@@ -227,15 +227,16 @@ class Workspace:
 
 
 def attn_head_pad(Dh):
-    """Head size the attention kernel runs at: 64 and 128 natively; smaller heads (the U-Net's 32 / 40) zero-padded to 64, anything
-    between (DiT-XL/2: 72, the U-Net's 80) to 128."""
-    return 64 if Dh <= 64 else 128
+    """Head size the attention kernel runs at: 64, 80 and 128 natively; smaller heads (the U-Net's 32 / 40) zero-padded to 64, 65 - 80
+    (DiT-XL/2: 72, the U-Net's 80) stored 80 wide (r6: the K / V^T stream of such a launch is what bounds it, 80 wide is 5/8 of the
+    bytes of 128 wide), anything above to 128."""
+    return 64 if Dh <= 64 else (80 if Dh <= 80 else 128)
 
 
 def attn_out_dim(Dh):
     """Width of one head in the attention OUTPUT: the kernel writes compact heads for the padded sizes it knows (72 -> 72, ABI 8),
     the stored width otherwise."""
-    return Dh if Dh in (64, 72, 128) else attn_head_pad(Dh)
+    return Dh if Dh in (64, 72, 80, 128) else attn_head_pad(Dh)
 
 
 def pad_head_columns(w, H, Dh):

@@ -33,6 +33,20 @@ __global__ __launch_bounds__(256) void probe(const float* in, unsigned long long
     asm volatile("v_mov_b32 %0, %1" : "=v"(we) : "v"(w.y));
     f2 wq = {we, we};
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d_ev) : "v"(t), "v"(wq), "v"(acc)); // the same from the LOW half of another pair
+    if (MIX & 8) {
+      // the exact shape of the failing gather code: two packed multiplies by the pair's LOW half, then two packed FMAs by its HIGH half, the
+      // other sources fresh from memory
+      const f4 ta = *reinterpret_cast<const f4*>(in + (((gi + it) * 4) & 0xffffc));
+      const f4 tb = *reinterpret_cast<const f4*>(in + (((gi + it) * 4 + 64) & 0xffffc));
+      f2 a0 = {ta.x, ta.y}, a1 = {ta.z, ta.w}, b0 = {tb.x, tb.y}, b1 = {tb.z, tb.w}, p0, p1;
+      asm volatile("v_pk_mul_f32 %0, %2, %6 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %6 op_sel_hi:[1,0]\n\t"
+                   "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %1, %5, %6, %1 op_sel:[0,1,0]"
+                   : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(wp));
+      const float q0 = __builtin_fmaf(tb.x, w.y, ta.x * w.x), q1 = __builtin_fmaf(tb.y, w.y, ta.y * w.x);
+      const float q2 = __builtin_fmaf(tb.z, w.y, ta.z * w.x), q3 = __builtin_fmaf(tb.w, w.y, ta.w * w.x);
+      nb_hi += (__float_as_uint(p0.x) != __float_as_uint(q0)) + (__float_as_uint(p0.y) != __float_as_uint(q1)) +
+               (__float_as_uint(p1.x) != __float_as_uint(q2)) + (__float_as_uint(p1.y) != __float_as_uint(q3));
+    }
     const float r0 = __builtin_fmaf(t.x, w.y, acc.x), r1 = __builtin_fmaf(t.y, w.y, acc.y);
     nb_hi += (__float_as_uint(d_hi.x) != __float_as_uint(r0)) + (__float_as_uint(d_hi.y) != __float_as_uint(r1));
     nb_ev += (__float_as_uint(d_ev.x) != __float_as_uint(r0)) + (__float_as_uint(d_ev.y) != __float_as_uint(r1));
@@ -80,6 +94,9 @@ int main() {
     if (run<3>(din, dbad, dsink, 16384, "several waves per SIMD")) return 1;
     if (run<7>(din, dbad, dsink, 16384, "several waves per SIMD")) return 1;
     if (run<7>(din, dbad, dsink, 100 * 1024, "ONE wave per SIMD (100 KB LDS)")) return 1;
+    if (run<8>(din, dbad, dsink, 16384, "gather sequence, several waves")) return 1;
+    if (run<15>(din, dbad, dsink, 16384, "gather sequence + all, several waves")) return 1;
+    if (run<15>(din, dbad, dsink, 42 * 1024, "gather sequence + all, 3 per SIMD")) return 1;
   }
   return 0;
 }
