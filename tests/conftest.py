@@ -52,3 +52,12 @@ def hip_lib():
     ge.build()
     from ln3diff_amd import _lib
     return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def hip_lib_path():
+    """Path of the built in-tree library (build() cross-compiles without a GPU); nothing is dlopen'ed for compute."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.LIB
