@@ -246,7 +246,8 @@ def attention_probe(dev, n_net, H=16, N=768, Dh=64, iters=20, Nq=None):
     from ln3diff_amd import ops
     Nq = Nq or N
     Dh_true = Dh
-    Dh = 64 if Dh <= 64 else 128                   # head sizes like DiT-XL/2's 72 sit in zero-padded 128-wide rows (as in the model)
+    from ln3diff_amd.dit.dit_models_xformers import attn_head_pad
+    Dh = attn_head_pad(Dh)                         # as the model stores them: DiT-XL/2's 72-wide heads sit in zero-padded 80-wide rows (r6; 128 before)
     q = torch.randn(n_net, H, Nq, Dh, device=dev).to(torch.bfloat16)
     k = torch.randn(n_net, H, N, Dh, device=dev).to(torch.bfloat16)
     vt = torch.randn(n_net, H, Dh, N, device=dev).to(torch.bfloat16)
