@@ -110,7 +110,7 @@ int ln3d_gemm_heads_norm_fusable(int M, int N, int tokens, int head_dim, int hea
  *   16-group stored in the order [0-3, 8-11, 4-7, 12-15] (position p holds key p with bits 2,3 swapped) - the layout
  *   ln3d_gemm_bf16's LN3D_EPI_HEADS epilogue emits for transposed outputs.
  *   O  : bf16 [B, Nq, ldo]  (only rows q < Nq written).  Keys k >= Nk are masked; Nk_pad % 64 == 0 and
- *   the padded K / Vt entries must be finite (zero).  Dh in {64, 128}.
+ *   the padded K / Vt entries must be finite (zero).  Dh in {64, 80, 128} (80: r6, the stored width of 65 - 80 wide heads).
  * Replaces xformers.ops.memory_efficient_attention at vit/vision_transformer.py:118,
  *   ldm/modules/attention.py:297 and ldm/modules/diffusionmodules/model.py:262.
  */
@@ -121,7 +121,7 @@ typedef struct {
   float scale;
   int causal;              /* 1: query i attends keys <= i (CLIP text tower; Dh 64 and Nk <= 128 only); 0: full attention */
   int Dh_true;             /* ABI 8: true head size when Q / K / Vt rows are stored zero-padded to Dh (0 or Dh = not padded).  72 with
-                            * Dh 128 (DiT-XL/2, dit/dit_trilatent.py:272: hidden 1152 / 16 heads): the products skip the padding and
+                            * Dh 80 (r6) or Dh 128 (DiT-XL/2, dit/dit_trilatent.py:272: hidden 1152 / 16 heads): the products skip the padding and
                             * O is written COMPACT, O[b, q, h*Dh_true + d] with ldo = H*Dh_true, so the projection behind it
                             * contracts over H*Dh_true.  Other values: LN3D_ERR_UNSUPPORTED. */
 } ln3d_attn_args;
@@ -155,8 +155,8 @@ int ln3d_image_preprocess(const float* x, float* out, float* tmp, int N, int C, 
 
 /* per-head RMSNorm of q / k in place: x[row, 0:Dh] * rsqrt(mean(x^2)+eps) * w   (qk_norm,
  * vit/vision_transformer.py:81-82,116; ldm/modules/attention.py:264-265,294; dit/norm.py:27-40).
- * Dh = stored row width (64 or 128); true_dim = the head size the mean is taken over when heads are zero-padded to Dh
- * (DiT-XL: 72 in rows of 128; w then has Dh entries, zero beyond true_dim); 0 = Dh */
+ * Dh = stored row width (64, 80 or 128); true_dim = the head size the mean is taken over when heads are zero-padded to Dh
+ * (DiT-XL: 72 in rows of 80; w then has Dh entries, zero beyond true_dim); 0 = Dh */
 int ln3d_rmsnorm_heads_bf16(void* x, const float* w, int64_t rows, int Dh, int true_dim, float eps, void* stream);
 
 /* ---------------------------------------------------------------- norm + modulation

@@ -665,26 +665,36 @@ __global__ __launch_bounds__(64 * RENDER_WPB, RENDER_OCC) void render_kernel(Ren
     // upper bound in the sorted LDS copy (7 dependent reads); what is left per fine element k is one compare for the coarse lanes
     // and the (<, ==) pair for the fine ones, accumulated through the carry-in of v_addc (the tie rule "k < lane" is a constant
     // lane mask on the scalar side).  Identical ranks by construction; rays with a swapped neighbour pair or a NaN take the full count.
+    // r6: two more cuts on the common path.  (a) The coarse ranks need no compares at all: with the coarse depths in order, fine sample k lies
+    // behind exactly pos_k coarse ones (zc_j <= zf_k <=> j < pos_k), so #(zf_k < zc_j) = #(k: pos_k <= j) - a 65-bin histogram of the
+    // positions (one LDS atomic per lane) and a wave prefix sum instead of 64 compares + 64 carry adds.  (b) Among the fine samples only
+    // the strict compare is counted; two bit-equal fine depths (the only case the tie rule exists for) would then share a rank, which
+    // shows as a rank total below 0 + 1 + ... + 127 = 8128 - checked with one wave sum, and such a ray takes the full count below like the
+    // grazing ones.  Identical ranks by construction on every ray that stays on this path.
     const bool in_order = (zc <= zn) && (zf == zf);
-    if (__builtin_amdgcn_ballot_w64(!in_order) == 0ull) {
+    bool fast = __builtin_amdgcn_ballot_w64(!in_order) == 0ull;
+    if (fast) {
       int pos = 0;
 #pragma unroll
       for (int s2 = 32; s2 >= 1; s2 >>= 1) pos += (zc_s[pos + s2 - 1] <= zf) ? s2 : 0;
       pos += (zc_s[pos] <= zf) ? 1 : 0;
-      rc = lane; rf = pos;
-#define RANK_STEP(av, k)                                                                                       \
-      {                                                                                                        \
-        add_mask(rc, __builtin_amdgcn_ballot_w64((av) < zc));                                                  \
-        const uint64_t lt_ = __builtin_amdgcn_ballot_w64((av) < zf), eq_ = __builtin_amdgcn_ballot_w64((av) == zf); \
-        add_mask(rf, lt_ | (eq_ & ((k) < 63 ? (~0ull << (((k) + 1) & 63)) : 0ull)));                           \
-      }
+      int* cnt = reinterpret_cast<int*>(feat + 768);                         // 65 bins behind the five rank planes
+      cnt[lane] = 0;
+      if (lane == 0) cnt[64] = 0;
+      wave_sync();
+      atomicAdd(&cnt[pos], 1);
+      wave_sync();
+      rc = lane + (int)wave_incl_sum((float)cnt[lane], lane);                // counts <= 64: exact in fp32
+      rf = pos;
 #pragma unroll
       for (int k = 0; k < NS; k += 4) {
         const float4 a = *reinterpret_cast<const float4*>(zf_s + k);
-        RANK_STEP(a.x, k + 0) RANK_STEP(a.y, k + 1) RANK_STEP(a.z, k + 2) RANK_STEP(a.w, k + 3)
+        add_mask(rf, __builtin_amdgcn_ballot_w64(a.x < zf)); add_mask(rf, __builtin_amdgcn_ballot_w64(a.y < zf));
+        add_mask(rf, __builtin_amdgcn_ballot_w64(a.z < zf)); add_mask(rf, __builtin_amdgcn_ballot_w64(a.w < zf));
       }
-#undef RANK_STEP
-    } else {
+      fast = wave_total((float)(rc + rf)) == 8128.0f;                        // 64 ranks + 64 ranks, all <= 127: exact in fp32
+    }
+    if (!fast) {
       rc = 0; rf = 0;
 #pragma unroll 4
       for (int k = 0; k < NS; k += 4) {

@@ -277,3 +277,31 @@ def test_render_repeatability_sweep_100_scenes(hip_lib):
             for k in keys:
                 assert torch.equal(ref[k], o[k]), (scene, V, res, rad, el, k, int((ref[k] != o[k]).sum()))
     print('repeatability sweep: 100 scenes, %.1f M rays x 3 launches, 0 differing values' % (rays / 1e6))
+
+
+def test_render_with_bit_equal_fine_depths_vs_oracle(hip_lib):
+    """r6: the merge's fast path counts the fine samples strictly and detects two bit-equal fine depths by the rank total (such a ray
+    takes the full count).  Every ray of this scene carries such a pair (u_fine[:, 7] = u_fine[:, 3]), plus a triple on half of them:
+    the images must match the CPU oracle (which sorts) like any other scene, and repeat bitwise."""
+    from oracle import render as orender
+    from ln3diff_amd.nsr.triplane import Triplane, draw_render_noise
+    from ln3diff_amd.synth import synth_input, orbit_cameras
+    res, V = 24, 2
+    tp = Triplane(img_resolution=res)
+    sd = _decoder_sd(4.0)
+    tp.decoder.load_state_dict(sd)
+    tp = tp.cuda()
+    planes = synth_input('planes', (V, 96, 128, 128), 3, 4.0)
+    cams = orbit_cameras(V)
+    gen = torch.Generator().manual_seed(11)
+    jitter, u_fine = draw_render_noise(V, res * res, 64, generator=gen)
+    u_fine = u_fine.clone()
+    u_fine[:, 7] = u_fine[:, 3]
+    u_fine[::2, 40] = u_fine[::2, 3]
+    ref = orender.triplane_render(planes, {k: v.float() for k, v in sd.items()}, cams, res, jitter.unsqueeze(-1), u_fine)
+    a = tp(planes.cuda(), cams.cuda(), jitter=jitter, u_fine=u_fine)
+    b = tp(planes.cuda(), cams.cuda(), jitter=jitter, u_fine=u_fine)
+    for key in ('image_raw', 'image_depth', 'weights_samples'):
+        assert torch.equal(a[key], b[key]), key
+        e = rel_l2(a[key].cpu(), ref[key])
+        assert e < 2e-3, (key, e)
