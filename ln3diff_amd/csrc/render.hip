@@ -240,10 +240,15 @@ __device__ __forceinline__ float softplus20_hw(float x) {
 }
 __device__ __forceinline__ float exp_neg_hw(float t) { return __builtin_amdgcn_exp2f(t * -1.4426950408889634f); }   // exp(-t)
 
+// -DLN3D_RENDER_OPSEL_REPRO (tools/r6_opsel_repro.sh, never the library): without the copy - the reproducer of profiles/r6_render_opsel.md
 __device__ __forceinline__ float even_reg(float x) {
+#ifdef LN3D_RENDER_OPSEL_REPRO
+  return x;
+#else
   float r;
   asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
   return r;
+#endif
 }
 
 __device__ __forceinline__ void shade64(const RenderP& p, const float* __restrict__ planes, char* wl, const char* cimg,

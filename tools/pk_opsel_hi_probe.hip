@@ -80,6 +80,72 @@ static int run(const float* din, unsigned long long* dbad, float* dsink, int lds
   return 0;
 }
 
+// Second form: the checker waves (the failing gather sequence, sources fresh from LDS / memory) share their SIMDs with waves that run OTHER
+// instruction streams out of phase - an MFMA chain, transcendentals + scalar-rate VALU, LDS + global traffic - as in the ray-marcher, where the
+// waves of a SIMD are at different points of the ray loop.
+__global__ __launch_bounds__(256) void probe_roles(const float* in, unsigned long long* bad, float* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int gi = blockIdx.x * blockDim.x + tid;
+  const int role = blockIdx.x & 3;
+  for (int i = tid; i < 256 * 4; i += blockDim.x) lds[i] = in[(gi * 7 + i) & 0xfffff] * 0.5f + 0.25f;
+  __syncthreads();
+  float acc = 0.f;
+  if (role == 0) {
+    unsigned long long nb = 0;
+    for (int it = 0; it < iters; ++it) {
+      const f4 w = *reinterpret_cast<const f4*>(lds + ((tid + it) & 255) * 4);
+      f2 wp = {w.x, w.y}, wq = {w.z, w.w};
+      const f4 ta = *reinterpret_cast<const f4*>(in + (((gi + it * 977) * 4) & 0xffffc));
+      const f4 tb = *reinterpret_cast<const f4*>(in + (((gi + it * 977) * 4 + 64) & 0xffffc));
+      const f4 tc = *reinterpret_cast<const f4*>(in + (((gi + it * 977) * 4 + 128) & 0xffffc));
+      f2 a0 = {ta.x, ta.y}, a1 = {ta.z, ta.w}, b0 = {tb.x, tb.y}, b1 = {tb.z, tb.w}, c0 = {tc.x, tc.y}, c1 = {tc.z, tc.w}, p0, p1;
+      asm volatile("v_pk_mul_f32 %0, %2, %8 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %8 op_sel_hi:[1,0]\n\t"
+                   "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %1, %5, %8, %1 op_sel:[0,1,0]\n\t"
+                   "v_pk_fma_f32 %0, %6, %9, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %7, %9, %1 op_sel_hi:[1,0,1]"
+                   : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1), "v"(wp), "v"(wq));
+      const float q0 = __builtin_fmaf(tc.x, w.z, __builtin_fmaf(tb.x, w.y, ta.x * w.x)), q1 = __builtin_fmaf(tc.y, w.z, __builtin_fmaf(tb.y, w.y, ta.y * w.x));
+      const float q2 = __builtin_fmaf(tc.z, w.z, __builtin_fmaf(tb.z, w.y, ta.z * w.x)), q3 = __builtin_fmaf(tc.w, w.z, __builtin_fmaf(tb.w, w.y, ta.w * w.x));
+      nb += (__float_as_uint(p0.x) != __float_as_uint(q0)) + (__float_as_uint(p0.y) != __float_as_uint(q1)) +
+            (__float_as_uint(p1.x) != __float_as_uint(q2)) + (__float_as_uint(p1.y) != __float_as_uint(q3));
+      acc += p0.x + p1.y;
+    }
+    if (nb) atomicAdd(&bad[lane >> 4], nb);
+  } else if (role == 1) {
+    f32x16 m;
+    for (int r = 0; r < 16; ++r) m[r] = 0.f;
+    union { float f[4]; bf16x8 v; } a, b;
+    a.f[0] = in[gi & 0xfffff]; a.f[1] = 1.f; a.f[2] = 2.f; a.f[3] = 3.f; b.f[0] = 0.5f; b.f[1] = 0.25f; b.f[2] = in[(gi + 9) & 0xfffff]; b.f[3] = 1.f;
+    for (int it = 0; it < iters * 2; ++it) { m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, m, 0, 0, 0); if ((it & 7) == 7) { a.f[0] = m[3] * 1e-20f; } }
+    for (int r = 0; r < 16; ++r) acc += m[r] * 1e-30f;
+  } else if (role == 2) {
+    float t = in[gi & 0xfffff] * 0.5f + 1.0f;
+    for (int it = 0; it < iters * 4; ++it) { t = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(t)) * 0.7f + 0.3f; t = t * 0.999f + (float)(it & 3) * 1e-3f; }
+    acc = t;
+  } else {
+    float t = 0.f;
+    for (int it = 0; it < iters * 2; ++it) {
+      const f4 w = *reinterpret_cast<const f4*>(lds + ((tid * 3 + it) & 255) * 4);
+      const f4 g = *reinterpret_cast<const f4*>(in + (((gi * 5 + it * 131) * 4) & 0xffffc));
+      t += w.x * g.y + w.w * g.z;
+      lds[1024 + ((tid * 5 + it) & 1023)] = t;
+    }
+    acc = t;
+  }
+  sink[gi] = acc;
+}
+
+static int run_roles(const float* din, unsigned long long* dbad, float* dsink, int lds_bytes, const char* what) {
+  CK(hipMemset(dbad, 0, 64));
+  CK(hipFuncSetAttribute((const void*)probe_roles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+  hipLaunchKernelGGL(probe_roles, dim3(256 * 16), dim3(256), lds_bytes, 0, din, dbad, dsink, 4000);
+  CK(hipDeviceSynchronize());
+  unsigned long long h[8];
+  CK(hipMemcpy(h, dbad, 64, hipMemcpyDeviceToHost));
+  printf("roles  %-34s gather sequence mismatches by 16-lane pass: %llu %llu %llu %llu\n", what, h[0], h[1], h[2], h[3]);
+  return 0;
+}
+
 int main() {
   const int N = 1 << 20;
   std::vector<float> h(N);
@@ -97,6 +163,8 @@ int main() {
     if (run<8>(din, dbad, dsink, 16384, "gather sequence, several waves")) return 1;
     if (run<15>(din, dbad, dsink, 16384, "gather sequence + all, several waves")) return 1;
     if (run<15>(din, dbad, dsink, 42 * 1024, "gather sequence + all, 3 per SIMD")) return 1;
+    if (run_roles(din, dbad, dsink, 16384, "mixed roles, several waves per SIMD")) return 1;
+    if (run_roles(din, dbad, dsink, 42 * 1024, "mixed roles, 3 workgroups per CU")) return 1;
   }
   return 0;
 }
