@@ -778,19 +778,23 @@ __global__ void render_finalize_kernel(float* depth, const uint32_t* scal_u, int
 // reference's entry points select - depth_resolution / depth_resolution_importance in {48, 64, 80, 96, 128}, numeric ray_start /
 // ray_end (ShapeNet, FFHQ), no bbox filter - and the per-sample outputs of return_meta (weights, all_coords, feature_volume:
 // renderer.py:283-300) go through this kernel: still one wavefront per ray and the same gather + MFMA decoder (shade64, up to two
-// passes of 64 points per sampling stage), but the per-ray arrays live in the wave's LDS (20 KB) and a lane owns CONSECUTIVE
+// passes of 64 points per sampling stage), but the per-ray arrays live in the wave's LDS (15 KB) and a lane owns CONSECUTIVE
 // intervals of the march (2 of the <= 127 coarse ones, 4 of the <= 255 merged ones), so any sample count <= 128 + 128 fits one code
 // path.  Evaluation order follows the reference operator by operator like the kernel above; it is not tuned beyond that.
 #define GEN_MAXS 128
 #define G_ZC 2048               // float offsets inside the wave's region: [0, 2048) is shade64's feature tile
 #define G_ZF (G_ZC + 5 * GEN_MAXS)
-#define G_SRT (G_ZF + 5 * GEN_MAXS)
-#define G_W (G_SRT + 5 * 2 * GEN_MAXS)
+// r6: the merged, depth-sorted planes {z, sigma, r, g, b} x 256 (1 280 floats) live in the feature tile - they are written behind the ray's
+// last shade64 and read until the ray ends, the tile is written again by the next ray's first shade64 (a wave_sync in between).  15 KB per wave
+// instead of 20: 70.5 KB per workgroup, so TWO workgroups share a CU (two waves per SIMD at the kernel's 252 VGPRs) where one did.
+#define G_SRT 0
+#define G_W (G_ZF + 5 * GEN_MAXS)
 #define G_CDF (G_W + 2 * GEN_MAXS)
 #define G_BIN (G_CDF + GEN_MAXS)
 #define GEN_WAVE_FLOATS (G_BIN + GEN_MAXS)
 #define GEN_LDS_BYTES (4 * GEN_WAVE_FLOATS * 4 + DEC_BYTES)
-static_assert(GEN_LDS_BYTES <= 160 * 1024, "one workgroup of the generic ray-marcher per CU");
+static_assert(5 * 2 * GEN_MAXS <= WAVE_LDS_FLOATS, "the merged planes fit the feature tile");
+static_assert(2 * GEN_LDS_BYTES <= 160 * 1024, "two workgroups of the generic ray-marcher per CU");
 
 // MipRayMarcher2.run_forward over n samples held as 5 planes {z, sigma, r, g, b} with plane stride PS in LDS: lane owns intervals
 // IPL * lane .. IPL * lane + IPL - 1.  Returns the five sums (same value in every lane) and T behind the last interval; writes the
