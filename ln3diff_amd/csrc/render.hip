@@ -50,11 +50,15 @@
 #define MAX_GROUPS ((LN3D_RENDER_SCRATCH_FLOATS - GRP_OFF) / GRP_WORDS)
 static_assert(MAX_GROUPS >= 1024, "room for the per-call range records");
 
+// r6: 8 wavefronts per workgroup at 4 per SIMD (two 74 KB workgroups per CU).  r4 measured that occupancy 8 % SLOWER (128 VGPRs cost 28 spills
+// then); with the r6 gather (setup in LDS, scalar-base loads, lane-constant addresses) and the decoder run behind the gather the kernel
+// fits 128 VGPRs with 6 spilled loop invariants, and the fourth wave pays: 0.636 -> 0.62 ms per 256^2 view, 2.34 -> 2.25 at 512^2, 0.212 -> 0.20 at
+// 128^2 (profiles/r6_render_occ4.log; bit-identical images).
 #ifndef RENDER_OCC
-#define RENDER_OCC 3
+#define RENDER_OCC 4
 #endif
 #ifndef RENDER_WPB
-#define RENDER_WPB 4          // wavefronts (= rays in flight) per workgroup of render_kernel; they share one LDS copy of the decoder image
+#define RENDER_WPB 8          // wavefronts (= rays in flight) per workgroup of render_kernel; they share one LDS copy of the decoder image
 #endif
 #ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
 #define LN3D_RENDER_ABL 0
@@ -450,8 +454,12 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   float4 tA[12];
   // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
   // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
-#ifndef LN3D_RENDER_SEQ   // bench-only: 1 = the decoder of point tile 0 behind the whole gather instead of under its second half
-#define LN3D_RENDER_SEQ 0
+  // LN3D_RENDER_SEQ 1 (shipped): the decoder of both point tiles behind the whole gather.  0 (bench builds) = the decoder of tile 0 in four
+  // pieces under the texel loads of gather iterations 4 - 7: built first this round, bit-identical, and measured NO faster (0.655 vs 0.641 -
+  // 0.655 ms per view) at 23 more VGPRs - the decoder is 0.05 ms of the kernel and the texel loads it would hide under are an L1-path
+  // throughput term (profiles/r6_render_abl.log) - so the sequential form, which fits 4 waves per SIMD, is the one that ships.
+#ifndef LN3D_RENDER_SEQ
+#define LN3D_RENDER_SEQ 1
 #endif
 #pragma unroll 1
   for (int it = 0; it < (LN3D_RENDER_SEQ ? 8 : 4); ++it) {
@@ -459,9 +467,8 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     reduce(it, tA);
   }
   wave_sync();
-  // r6: points 0 - 31 are complete: their decoder runs UNDER the texel loads of points 32 - 63 (a piece per gather iteration, between
-  // the issue of the iteration's 12 loads and their first use), so half of the decoder's matrix / transcendental chain costs no
-  // time of its own.  Same arithmetic in the same order per point: bit-identical to the r5 kernel.
+  // LN3D_RENDER_SEQ 0 only: points 0 - 31 are complete and their decoder runs UNDER the texel loads of points 32 - 63 (a piece per gather
+  // iteration, between the issue of the iteration's 12 loads and their first use).  Same arithmetic in the same order per point: bit-identical.
   f32x16 hacc, oacc;
 #define SB0_ __builtin_amdgcn_sched_barrier(0)
   if constexpr (LN3D_RENDER_SEQ) {
