@@ -50,15 +50,15 @@
 #define MAX_GROUPS ((LN3D_RENDER_SCRATCH_FLOATS - GRP_OFF) / GRP_WORDS)
 static_assert(MAX_GROUPS >= 1024, "room for the per-call range records");
 
-// r6: 8 wavefronts per workgroup at 4 per SIMD (two 74 KB workgroups per CU).  r4 measured that occupancy 8 % SLOWER (128 VGPRs cost 28 spills
-// then); with the r6 gather (setup in LDS, scalar-base loads, lane-constant addresses) and the decoder run behind the gather the kernel
-// fits 128 VGPRs with 6 spilled loop invariants, and the fourth wave pays: 0.636 -> 0.62 ms per 256^2 view, 2.34 -> 2.25 at 512^2, 0.212 -> 0.20 at
-// 128^2 (profiles/r6_render_occ4.log; bit-identical images).
+// 4 wavefronts per workgroup, 3 per SIMD.  r6 re-measured 8-wave workgroups at 4 per SIMD (-DRENDER_WPB=8 -DRENDER_OCC=4): with the r6 gather and
+// the decoder behind the gather the kernel fits 128 VGPRs with 6 spilled loop invariants (r4: 28 spills, 8 % slower) and the isolated loop gains
+// 2 - 4 % (0.630 -> 0.62 ms per 256^2 view, 2.37 -> 2.25 at 512^2) - but inside the pipelines it is level on configs[1] (+0.2 %) and 0.8 % BEHIND on
+// configs[2] (768 views of 32 plane sets per launch), so the no-spill form ships (profiles/r6_render_occ4.log, r6_render_insitu.log).
 #ifndef RENDER_OCC
-#define RENDER_OCC 4
+#define RENDER_OCC 3
 #endif
 #ifndef RENDER_WPB
-#define RENDER_WPB 8          // wavefronts (= rays in flight) per workgroup of render_kernel; they share one LDS copy of the decoder image
+#define RENDER_WPB 4          // wavefronts (= rays in flight) per workgroup of render_kernel; they share one LDS copy of the decoder image
 #endif
 #ifndef LN3D_RENDER_ABL   // bench-only ablations (tools/render_bench.hip): 1 = no decoder MLP, 2 = no texel loads, 4 = no compositing
 #define LN3D_RENDER_ABL 0
@@ -455,9 +455,10 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
   // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
   // LN3D_RENDER_SEQ 1 (shipped): the decoder of both point tiles behind the whole gather.  0 (bench builds) = the decoder of tile 0 in four
-  // pieces under the texel loads of gather iterations 4 - 7: built first this round, bit-identical, and measured NO faster (0.655 vs 0.641 -
-  // 0.655 ms per view) at 23 more VGPRs - the decoder is 0.05 ms of the kernel and the texel loads it would hide under are an L1-path
-  // throughput term (profiles/r6_render_abl.log) - so the sequential form, which fits 4 waves per SIMD, is the one that ships.
+  // pieces under the texel loads of gather iterations 4 - 7: built first this round, bit-identical, and measured NO faster - isolated 0.636 vs
+  // 0.630 ms per 256^2 view, 0.212 vs 0.198 at 128^2, 2.34 vs 2.37 at 512^2; in the pipelines configs[1] level, configs[2] 0.5 % behind - at 23 more
+  // VGPRs: the decoder is 0.05 ms of the kernel and the texel loads it would hide under are an L1-path throughput term
+  // (profiles/r6_render_abl.log, r6_render_insitu.log).
 #ifndef LN3D_RENDER_SEQ
 #define LN3D_RENDER_SEQ 1
 #endif
