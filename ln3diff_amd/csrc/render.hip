@@ -10,7 +10,8 @@
 // Wave mapping (64 lanes = the 64 coarse / 64 fine samples of one ray):
 //  * gather phase : 8 lanes per sample point, lane (g = lane>>3, c4 = lane&7) fetches channels 4c4..4c4+3
 //    of the 12 taps of point 8*it+g from CHANNEL-LAST planes [3][H][W][32] -> every wave-level load
-//    instruction touches 8 fully-used 128-B texels (coalesced), instead of 64 partially-used lines.
+//    instruction touches 8 fully-used 128-B texels (coalesced), instead of 64 partially-used lines.  The point's tap offsets /
+//    weights (computed once by its owner lane) reach the 8 lanes through the wave's LDS tile (r6), the loads take a scalar base.
 //    The interpolated 32-vector goes to a per-wave LDS tile as TWO bf16 rows (hi = truncated fp32, lo = bf16(f - hi)),
 //    128 bytes per point, 16-byte chunks XOR-swizzled ...
 //  * MLP phase    : ... which is the B operand of v_mfma_f32_32x32x16_bf16: the 32 -> 64 -> 4 decoder of the wave's 64 points
@@ -272,8 +273,8 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   const int plane_stride = p.H * p.W * 32;
   // ---- bilinear setup, ONCE per point (this lane's own point): per plane 4 clamped tap offsets (bytes, channel 0 of the texel)
   // and 4 tap weights with the zero-padding mask folded in.  The gather below has 8 lanes cooperate on one point's texels (one
-  // 128-B line per tap per point); they fetch the owner's setup with ds_bpermute instead of recomputing it 8 times - the
-  // address / weight arithmetic was 200 of the 252 VALU instructions of a gather iteration (profiles/r2_render_pmc.md).
+  // 128-B line per tap per point); they fetch the owner's setup (through the LDS tile, below; r2 - r5: ds_bpermute) instead of recomputing it
+  // 8 times - the address / weight arithmetic was 200 of the 252 VALU instructions of a gather iteration (profiles/r2_render_pmc.md).
   int toff[12];
   float tw[12];
 #pragma unroll
@@ -302,8 +303,7 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   // wave's LDS operations execute in program order) takes point s's 12 tap offsets + 12 tap weights as six 16-byte chunks, chunk c at
   // position c ^ (s & 7): the 8 rows a gather iteration reads (one per lane group g, every lane of the group the same address =
   // broadcast) sit in 8 different chunk positions, so both the b128 writes and the b128 reads are conflict-free.  6 + 8 x 6 LDS
-  // instructions per pass instead of 8 x 24, and the 24 setup registers are not live across the loop any more - which is what makes
-  // room for the decoder's accumulators beside the gather (below).
+  // instructions per pass instead of 8 x 24, and the 24 setup registers are not live across the loop any more.
   const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)wl;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) i32x4 lds_i4;
@@ -392,7 +392,8 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
     *reinterpret_cast<uint2*>(wrow + it * 1024 + ((it & 1) ? 0 : 64)) = lv;
   };
   // ---- the 32 -> 64 -> 4 decoder of one 32-point tile in four pieces (hidden tile jt = 0, 1: layer 1 + softplus, then its two k-steps of
-  // layer 2), so that the pieces of point tile 0 can be placed between the load issue and the load use of gather iterations 4 - 7
+  // layer 2): the LN3D_RENDER_SEQ=0 bench build places the pieces of point tile 0 between the load issue and the load use of gather
+  // iterations 4 - 7; the shipped build runs them back to back behind the gather
   const int l31 = lane & 31, hi = lane >> 5;
   const uint32_t cb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)cimg;
   auto mlp_l1 = [&](int pt, int jt, f32x16& hacc) {
@@ -452,8 +453,8 @@ __device__ __forceinline__ void shade64(const RenderP& p, const float* __restric
   };
   constexpr bool kMlp = !(LN3D_RENDER_ABL & 1);
   float4 tA[12];
-  // one iteration (8 points) at a time: double-buffering the 12 loads needs 244 VGPRs = 2 waves/SIMD, which measured slower
-  // (0.863 ms per 256^2 view) than 3 waves/SIMD covering each other's load latency (0.838)
+  // one iteration (8 points) at a time: double-buffering the 12 loads measured slower at 2 waves/SIMD (r2: 0.863 vs 0.838 ms per 256^2 view),
+  // and r6's ablations say why more loads in flight do not help: the texel loads are an L1-path THROUGHPUT term (profiles/r6_render_abl.log)
   // LN3D_RENDER_SEQ 1 (shipped): the decoder of both point tiles behind the whole gather.  0 (bench builds) = the decoder of tile 0 in four
   // pieces under the texel loads of gather iterations 4 - 7: built first this round, bit-identical, and measured NO faster - isolated 0.636 vs
   // 0.630 ms per 256^2 view, 0.212 vs 0.198 at 128^2, 2.34 vs 2.37 at 512^2; in the pipelines configs[1] level, configs[2] 0.5 % behind - at 23 more
