@@ -371,6 +371,61 @@ def test_attention_head_size_72_in_padded_rows(hip_lib, B, H, Nq, Nk):
         assert t72 < t128
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,Dh", [(2, 16, 768, 768, 72), (1, 3, 300, 1000, 72), (2, 5, 768, 1024, 80), (1, 2, 333, 77, 80), (16, 16, 768, 768, 72)])
+def test_attention_heads_stored_80_wide(hip_lib, B, H, Nq, Nk, Dh):
+    """r6: heads of 65 - 80 dims are stored 80 wide (attn_kernel<80, 2, DT>: 176-byte K pitch in LDS, 11 + 10 DMA instructions per stage dealt
+    3 / 3 / 3 / 3 / 3 / 2 / 2 / 2 to the waves with per-wave counted waits).  DiT-XL/2's 72 (compact [B, Nq, H * 72] output) and true 80-wide
+    heads, ragged query / key counts, a spiked key for the rescale branch: against fp32 torch on the same bf16 operands, against the 128-wide
+    storage of the same values (72), bitwise repeat; the XL/2-size case prints both timings and must be faster than the 128-wide one."""
+    from ln3diff_amd import ops
+    dev, Dp = 'cuda', 80
+    g = torch.Generator().manual_seed(Nq + Nk + B + Dh)
+    nqp, nkp = (Nq + 63) // 64 * 64, (Nk + 63) // 64 * 64
+
+    def operands(width):
+        gg = torch.Generator().manual_seed(Nq + Nk + B + Dh)
+        q = torch.zeros(B, H, nqp, width); k = torch.zeros(B, H, nkp, width); v = torch.zeros(B, H, nkp, width)
+        q[:, :, :Nq, :Dh] = torch.randn(B, H, Nq, Dh, generator=gg) * 1.5
+        k[:, :, :Nk, :Dh] = torch.randn(B, H, Nk, Dh, generator=gg) * 1.5
+        v[:, :, :Nk, :Dh] = torch.randn(B, H, Nk, Dh, generator=gg) + torch.arange(Dh) / Dh
+        k[:, :, Nk - 5] = q[:, :, 3] * 4.0
+        qb, kb, vb = (_bf(t).to(dev) for t in (q, k, v))
+        vt = vb.transpose(-1, -2)[..., ops.vt_key_order(nkp, dev)].contiguous()
+        return qb, kb, vb, vt
+
+    qb, kb, vb, vt = operands(Dp)
+    dt = Dh if Dh != Dp else 0
+    out = torch.full((B, Nq, H * Dh), float('nan'), device=dev, dtype=torch.bfloat16)
+    run80 = lambda o: ops.attention(qb, kb, vt, o, B, H, Nq, nqp, Nk, nkp, Dp, scale=Dh ** -0.5, dh_true=dt)
+    run80(out)
+    ref = _attn_ref(qb[:, :, :Nq, :Dh], kb[:, :, :Nk, :Dh], vb[:, :, :Nk, :Dh], Dh ** -0.5).permute(0, 2, 1, 3).reshape(B, Nq, H * Dh)
+    assert torch.isfinite(out.float()).all()
+    e = rel_l2(out.float(), ref)
+    assert e < 1e-2, e
+    out2 = torch.empty_like(out)
+    run80(out2)
+    assert torch.equal(out, out2)                                        # run-to-run determinism
+    if Dh == 72:                                                         # the same values in 128-wide rows: the r4 / r5 storage
+        q1, k1, _, vt1 = operands(128)
+        o128 = torch.empty_like(out)
+        run128 = lambda: ops.attention(q1, k1, vt1, o128, B, H, Nq, nqp, Nk, nkp, 128, scale=Dh ** -0.5, dh_true=Dh)
+        run128()
+        assert rel_l2(out.float(), o128.float()) < 2e-3
+        if B * H >= 256:
+            def t(fn):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 20 * 1e3
+            t80, t128 = t(lambda: run80(out)), t(run128)
+            print(f"XL/2 self-attention {B}x{H} heads {Nq}x{Nk}: 80-wide storage {t80:.1f} us, 128-wide {t128:.1f} us")
+            assert t80 < t128
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 256, 256), (1, 3, 512, 512), (5, 8, 768, 768), (19, 16, 768, 1024), (1, 2, 1280, 1280),
                                        (2, 1, 2048, 2048), (1, 12, 3072, 3072), (3, 2, 200, 512), (2, 3, 768, 2304)])
 def test_attention_streaming_kernel_shapes(ops, B, H, Nq, Nk):
