@@ -5,14 +5,16 @@ Mirrors the reference's sgm surface for this path (same class names / call signa
   DiscreteDenoiser+EpsScaling sgm/modules/diffusionmodules/denoiser.py:45-78, denoiser_scaling.py:29-37
   VanillaCFG                 sgm/modules/diffusionmodules/guiders.py:24-42
   EulerEDMSampler            sgm/modules/diffusionmodules/sampling.py:82-130,211-215
+  HeunEDMSampler, EulerAncestralSampler, DPMPP2SAncestralSampler, DPMPP2MSampler (r6)   sampling.py:133-170, 218-365
 The sigma tables are built on the host in fp64/fp32 exactly like the reference; the per-step work is one
 network call on [uc ; c] (2B) with the c_in scale folded into the patch-embed kernel, and ONE fused
 elementwise kernel for denoiser-combine + CFG + Euler update (ln3d_edm_euler_step).  Context K/V are
 computed once per call, not once per step.
 """
-import numpy as np
+import math
 import os
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -319,6 +321,174 @@ class EulerEDMSampler:
 
 
 _CAPTURE_STREAMS = {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# r6: the other samplers of sgm/modules/diffusionmodules/sampling.py (HeunEDMSampler 218-236, EulerAncestralSampler 133-170 / 239-246,
+# DPMPP2SAncestralSampler 249-287, DPMPP2MSampler 290-365).  None of the released launchers selects them; they are here so that a sampler
+# config of the reference's family resolves.  Host loops over the same device pieces as EulerEDMSampler's generic path: one closure call per
+# network evaluation (the CFG-doubled batch), every update ONE ln3d_lincomb launch with the guidance x_u + s (x_c - x_u) folded into its
+# coefficients (all of these updates are linear in x and the denoised halves).  sigma is one number per step (s_in * sigma in the reference),
+# so the step sizes are host scalars.  LinearMultistepSampler (scipy quadrature coefficients) is not built.
+def _closure(denoiser, network):
+    """(input, sigma, c) -> denoised [2B, ...]: the reference's lambda / BoundDenoiser as given, or DiscreteDenoiser + network= bound here."""
+    if network is not None and isinstance(denoiser, DiscreteDenoiser):
+        return lambda x, s, c: denoiser(network, x, s, c)
+    return denoiser
+
+
+class _LoopSampler:
+    def __init__(self, num_steps=250, guider=None, discretization=None, **_):
+        self.num_steps = num_steps
+        self.guider = guider or VanillaCFG(6.5)
+        self.discretization = discretization or LegacyDDPMDiscretization()
+
+    def _setup(self, denoiser, x, cond, uc, num_steps, network):
+        n = self.num_steps if num_steps is None else num_steps
+        sigmas = [float(v) for v in self.discretization(n, device="cpu")]
+        x = (x * float((1.0 + sigmas[0] ** 2.0) ** 0.5)).contiguous()
+        return n, sigmas, _closure(denoiser, network), (cond if uc is None else uc), x, x.shape[0], float(self.guider.scale)
+
+    def _den(self, call, x, sig, cond, uc, keep=False):
+        """the two halves (x_u, x_c) of the denoised CFG batch at noise level sig; keep = they must survive the next network call"""
+        B = x.shape[0]
+        out = call(*self.guider.prepare_inputs(x, x.new_ones([B]) * sig, cond, uc)).contiguous().float()
+        if keep:
+            out = out.clone()
+        return out[:B], out[B:]
+
+    @staticmethod
+    def _noise(x, i, step_noise):
+        return step_noise(i).to(x.device).float().contiguous() if step_noise is not None else torch.randn(x.shape, device=x.device)
+
+
+def _ancestral(sig, nxt, eta):
+    """sampling_utils.get_ancestral_step (sampling_utils.py:22-31) on scalars"""
+    if not eta:
+        return nxt, 0.0
+    up = min(nxt, eta * (nxt ** 2 * (sig ** 2 - nxt ** 2) / sig ** 2) ** 0.5)
+    return (nxt ** 2 - up ** 2) ** 0.5, up
+
+
+class HeunEDMSampler(EulerEDMSampler):
+    """sampling.py:218-236: EDMSampler's step (noise injection included) + the trapezoidal correction, a second network evaluation per step
+    except onto sigma = 0.  Always the generic loop (the fused network loop of EulerEDMSampler is a one-evaluation-per-step schedule)."""
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
+        n = self.num_steps if num_steps is None else num_steps
+        sig_t = self.discretization(n, device="cpu")
+        gammas = self._gammas(sig_t)
+        sigmas = [float(v) for v in sig_t]
+        call = _closure(denoiser, network)
+        uc = cond if uc is None else uc
+        x = (x * float((1.0 + sigmas[0] ** 2.0) ** 0.5)).contiguous()
+        B, sc = x.shape[0], float(self.guider.scale)
+        xe = torch.empty_like(x)
+        den = _LoopSampler._den
+        for i in range(n):
+            sig, nxt = sigmas[i], sigmas[i + 1]
+            if gammas[i] > 0:
+                sig = self._churn(x, sig, gammas[i], i, step_noise)
+            du, dc = den(self, call, x, sig, cond, uc, keep=True)
+            r = (nxt - sig) / sig
+            ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], xe)                       # the Euler step
+            if nxt < 1e-14:
+                x.copy_(xe)
+            else:                                                                                # x + dt ((x - D) / sig + (x_e - D2) / nxt) / 2
+                d2u, d2c = den(self, call, xe, nxt, cond, uc)
+                a, b = (nxt - sig) / (2.0 * sig), (nxt - sig) / (2.0 * nxt)
+                ops.lincomb(x, [x, du, dc, xe, d2u, d2c], [a, -a * (1.0 - sc), -a * sc, b, -b * (1.0 - sc), -b * sc], x)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
+
+class EulerAncestralSampler(_LoopSampler):
+    """sampling.py:133-170, 239-246: Euler step to sigma_down, then s_noise * sigma_up of fresh noise where the next sigma is not 0.
+    step_noise(i) ([B, ...] tensor) replaces the device draw of step i (parity runs; the reference draws at every step)."""
+
+    def __init__(self, eta=1.0, s_noise=1.0, **kw):
+        super().__init__(**kw)
+        self.eta, self.s_noise = float(eta), float(s_noise)
+
+    def _ancestral_noise(self, x, i, nxt, up, step_noise):
+        if nxt > 0.0:
+            ops.lincomb(x, [self._noise(x, i, step_noise)], [self.s_noise * up], x)
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
+        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        for i in range(n):
+            sig, nxt = sigmas[i], sigmas[i + 1]
+            down, up = _ancestral(sig, nxt, self.eta)
+            du, dc = self._den(call, x, sig, cond, uc)
+            r = (down - sig) / sig
+            ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], x)
+            self._ancestral_noise(x, i, nxt, up, step_noise)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
+
+class DPMPP2SAncestralSampler(EulerAncestralSampler):
+    """sampling.py:249-287: exponential-integrator midpoint step in t = -log sigma towards sigma_down (second evaluation at sigma(t + h / 2)),
+    the Euler step when sigma_down is 0, then the ancestral noise."""
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
+        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        x2 = torch.empty_like(x)
+        for i in range(n):
+            sig, nxt = sigmas[i], sigmas[i + 1]
+            down, up = _ancestral(sig, nxt, self.eta)
+            du, dc = self._den(call, x, sig, cond, uc)
+            if down < 1e-14:
+                r = (down - sig) / sig
+                ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], x)
+            else:
+                t, t_next = -math.log(sig), -math.log(down)
+                h = t_next - t
+                sm = t + 0.5 * h
+                m1, m2 = math.exp(-sm) / math.exp(-t), math.expm1(-0.5 * h)
+                m3, m4 = math.exp(-t_next) / math.exp(-t), math.expm1(-h)
+                ops.lincomb(None, [x, du, dc], [m1, -m2 * (1.0 - sc), -m2 * sc], x2)               # x2 = m1 x - m2 D
+                d2u, d2c = self._den(call, x2, math.exp(-sm), cond, uc)
+                ops.lincomb(None, [x, d2u, d2c], [m3, -m4 * (1.0 - sc), -m4 * sc], x)              # x = m3 x - m4 D2
+            self._ancestral_noise(x, i, nxt, up, step_noise)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
+
+class DPMPP2MSampler(_LoopSampler):
+    """sampling.py:290-365: second-order multistep - the previous step's denoised output extrapolates the current one by the ratio of the two
+    log-sigma steps; the first step and the step onto sigma = 0 are first order (that last step returns the denoised sample itself)."""
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, **_):
+        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        old = None
+        for i in range(n):
+            sig, nxt = sigmas[i], sigmas[i + 1]
+            du, dc = self._den(call, x, sig, cond, uc, keep=True)
+            t = -math.log(sig)
+            if nxt < 1e-14:                                   # t_next = +inf: mult1 = 0, mult2 = expm1(-inf) = -1
+                m1, m2, h = 0.0, -1.0, float('inf')
+            else:
+                h = -math.log(nxt) - t
+                m1, m2 = nxt / sig, math.expm1(-h)
+            if old is None or nxt < 1e-14:
+                ops.lincomb(None, [x, du, dc], [m1, -m2 * (1.0 - sc), -m2 * sc], x)
+            else:
+                r = (t + math.log(sigmas[i - 1])) / h
+                m3, m4 = 1.0 + 1.0 / (2.0 * r), 1.0 / (2.0 * r)
+                ops.lincomb(None, [x, du, dc, old[0], old[1]],
+                            [m1, -m2 * m3 * (1.0 - sc), -m2 * m3 * sc, m2 * m4 * (1.0 - sc), m2 * m4 * sc], x)
+            old = (du, dc)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
 
 
 def _capture_stream(dev):

@@ -95,6 +95,128 @@ def edm_euler_sample(net, z, cond, uc, num_steps=250, scale=6.5, trace=None, s_c
     return x
 
 
+# --------------------------------------------------------- the other samplers of sgm/modules/diffusionmodules/sampling.py (r6)
+def _bc(v, x):
+    return v.view(-1, *([1] * (x.ndim - 1)))
+
+
+def ancestral_step_sizes(sigma_from, sigma_to, eta=1.0):
+    """sampling_utils.get_ancestral_step (sampling_utils.py:22-31)."""
+    if not eta:
+        return sigma_to, torch.zeros_like(sigma_to)
+    sigma_up = torch.minimum(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def edm_heun_sample(net, z, cond, uc, num_steps=10, scale=6.5, trace=None, s_churn=0.0, s_tmin=0.0, s_tmax=float('inf'), s_noise=1.0,
+                    step_noise=None):
+    """HeunEDMSampler (sampling.py:82-130 + 218-236): the Euler step, then - unless every next sigma is 0 - a second denoiser call at
+    (x_euler, next_sigma) and the trapezoidal update x + dt (d + d_new) / 2."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    num_sigmas = len(sigmas)
+    for i in range(num_sigmas - 1):
+        sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        gamma = min(s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+        sigma_hat = sigma * (gamma + 1.0)
+        if gamma > 0:
+            eps = (step_noise(i) if step_noise is not None else torch.randn_like(x)) * s_noise
+            x = x + eps * _bc(sigma_hat ** 2 - sigma ** 2, x) ** 0.5
+        den = edm_denoise_cfg(net, x, sigma_hat, cond, uc, scale, table)
+        d = (x - den) / _bc(sigma_hat, x)
+        dt = _bc(nxt - sigma_hat, x)
+        x_e = x + dt * d
+        if torch.sum(nxt) < 1e-14:
+            x = x_e
+        else:
+            den2 = edm_denoise_cfg(net, x_e, nxt, cond, uc, scale, table)
+            d_new = (x_e - den2) / _bc(nxt, x)
+            x = torch.where(_bc(nxt, x) > 0.0, x + (d + d_new) / 2.0 * dt, x_e)
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
+def euler_ancestral_sample(net, z, cond, uc, num_steps=10, scale=6.5, eta=1.0, s_noise=1.0, step_noise=None, trace=None):
+    """EulerAncestralSampler (sampling.py:133-170, 239-246): Euler step to sigma_down, then sigma_up of fresh noise where next_sigma > 0.
+    The reference draws randn_like(x) at EVERY step (torch.where evaluates both branches): step_noise(i) is called for every i."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        sigma_down, sigma_up = ancestral_step_sizes(sigma, nxt, eta)
+        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
+        x = x + (x - den) / _bc(sigma, x) * _bc(sigma_down - sigma, x)
+        noise = step_noise(i) if step_noise is not None else torch.randn_like(x)
+        x = torch.where(_bc(nxt, x) > 0.0, x + noise * s_noise * _bc(sigma_up, x), x)
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
+def dpmpp2s_ancestral_sample(net, z, cond, uc, num_steps=10, scale=6.5, eta=1.0, s_noise=1.0, step_noise=None, trace=None):
+    """DPMPP2SAncestralSampler (sampling.py:249-287): the exponential-integrator midpoint step in t = -log sigma towards sigma_down
+    (a second denoiser call at sigma(t + h / 2)), Euler when sigma_down is 0, then the ancestral noise."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        sigma_down, sigma_up = ancestral_step_sizes(sigma, nxt, eta)
+        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
+        x_euler = x + (x - den) / _bc(sigma, x) * _bc(sigma_down - sigma, x)
+        if torch.sum(sigma_down) < 1e-14:
+            x = x_euler
+        else:
+            t, t_next = sigma.log().neg(), sigma_down.log().neg()
+            h = t_next - t
+            sm = t + 0.5 * h
+            m1, m2 = sm.neg().exp() / t.neg().exp(), (-0.5 * h).expm1()
+            m3, m4 = t_next.neg().exp() / t.neg().exp(), (-h).expm1()
+            x2 = _bc(m1, x) * x - _bc(m2, x) * den
+            den2 = edm_denoise_cfg(net, x2, sm.neg().exp(), cond, uc, scale, table)
+            x = torch.where(_bc(sigma_down, x) > 0.0, _bc(m3, x) * x - _bc(m4, x) * den2, x_euler)
+        noise = step_noise(i) if step_noise is not None else torch.randn_like(x)
+        x = torch.where(_bc(nxt, x) > 0.0, x + noise * s_noise * _bc(sigma_up, x), x)
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
+def dpmpp2m_sample(net, z, cond, uc, num_steps=10, scale=6.5, trace=None):
+    """DPMPP2MSampler (sampling.py:290-365): the second-order multistep form - the previous step's denoised output extrapolates the
+    current one (ratio r of the two log-sigma steps); first step and the step onto sigma = 0 are first order."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    old = None
+    for i in range(len(sigmas) - 1):
+        sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        prev = None if i == 0 else s_in * sigmas[i - 1]
+        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
+        t, t_next = sigma.log().neg(), nxt.log().neg()
+        h = t_next - t
+        m1, m2 = t_next.neg().exp() / t.neg().exp(), (-h).expm1()
+        x_std = _bc(m1, x) * x - _bc(m2, x) * den
+        if old is None or torch.sum(nxt) < 1e-14:
+            x = x_std
+        else:
+            r = (t - prev.log().neg()) / h
+            den_d = _bc(1 + 1 / (2 * r), x) * den - _bc(1 / (2 * r), x) * old
+            x = torch.where(_bc(nxt, x) > 0.0, _bc(m1, x) * x - _bc(m2, x) * den_d, x_std)
+        old = den
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
 # --------------------------------------------------------- guided_diffusion DDPM
 def linear_betas(T=1000):
     scale = 1000 / T

@@ -383,7 +383,74 @@ def sec_flow_fixed():
         save(f'flow_tiny_{method}{steps}', final=y_ref)
 
 
-SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim, 'flow_fixed': sec_flow_fixed}
+# ------------------------------------------------------------- r6: the other samplers of sgm/modules/diffusionmodules/sampling.py
+def sec_more_samplers():
+    """HeunEDMSampler (with and without churn), EulerAncestralSampler, DPMPP2SAncestralSampler, DPMPP2MSampler over the tiny T23D DiT:
+    the reference's own classes on CPU; the stochastic ones draw randn_like(x) once per step from the global generator (seed stored),
+    the oracle twins get the same stream re-drawn."""
+    print('== more samplers on the tiny T23D DiT')
+    from sgm.modules.diffusionmodules import sampling as S
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    m = build_t23d(128, 2, 2)
+    sd, _ = load_synth(m, 0)
+    B = 2
+    z = synth_input('z', (B, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (B, 77, 768), 41), 'vector': synth_input('v', (B, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    dc = {'target': 'sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization'}
+    gc = {'target': 'sgm.modules.diffusionmodules.guiders.VanillaCFG', 'params': {'scale': 6.5}}
+    den = DiscreteDenoiser(scaling_config={'target': 'sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling'},
+                           num_idx=1000, discretization_config=dc, do_append_zero=False, quantize_c_noise=True, flip=True)
+    calls = []
+
+    def net(x, t, c, **kw):
+        calls.append(int(t[0]))
+        return m(x, t, c)
+    run = lambda sampler: sampler(lambda x, s, c: den(net, x, s, c), z.clone(), cond, uc)
+    onet = lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2)
+    steps = 8
+
+    # Heun, deterministic and with churn
+    y_ref = run(S.HeunEDMSampler(discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))
+    n_calls = len(calls)
+    tr = []
+    y_or = osamp.edm_heun_sample(onet, z.clone(), cond, uc, steps, 6.5, tr)
+    check(f'HeunEDM {steps} steps final latent', y_or, y_ref, 2e-4)
+    save('heun_tiny_8', final=y_ref, mid=tr[steps // 2], net_calls=np.array(n_calls))
+    churn = dict(s_churn=3.0, s_tmin=0.5, s_tmax=10.0, s_noise=1.003)
+    torch.manual_seed(12)
+    y_ref = run(S.HeunEDMSampler(discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu', **churn))
+    sig = osamp.legacy_ddpm_sigmas(steps)
+    churned = [i for i in range(steps) if churn['s_tmin'] <= float(sig[i]) <= churn['s_tmax']]
+    torch.manual_seed(12)
+    draws = {i: torch.randn(B, 12, 32, 32) for i in churned}
+    y_or = osamp.edm_heun_sample(onet, z.clone(), cond, uc, steps, 6.5, None, step_noise=lambda i: draws[i], **churn)
+    check(f'HeunEDM {steps} steps with s_churn final latent', y_or, y_ref, 2e-4)
+    save('heun_tiny_8_churn', final=y_ref, churned=np.array(churned), noise_seed=np.array(12), **{k: np.array(v) for k, v in churn.items()})
+
+    # the ancestral pair: one randn_like(x) per step, in step order
+    for name, cls, fn, seed, kw in (('euler_ancestral_tiny_8', S.EulerAncestralSampler, osamp.euler_ancestral_sample, 13, dict(eta=1.0, s_noise=1.0)),
+                                    ('euler_ancestral_tiny_8_eta', S.EulerAncestralSampler, osamp.euler_ancestral_sample, 14, dict(eta=0.6, s_noise=1.01)),
+                                    ('dpmpp2s_tiny_8', S.DPMPP2SAncestralSampler, osamp.dpmpp2s_ancestral_sample, 15, dict(eta=1.0, s_noise=1.0))):
+        torch.manual_seed(seed)
+        y_ref = run(cls(discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu', **kw))
+        torch.manual_seed(seed)
+        draws = [torch.randn(B, 12, 32, 32) for _ in range(steps)]
+        tr = []
+        y_or = fn(onet, z.clone(), cond, uc, steps, 6.5, step_noise=lambda i: draws[i], trace=tr, **kw)
+        check(f'{cls.__name__} {kw} final latent', y_or, y_ref, 2e-4)
+        save(name, final=y_ref, mid=tr[steps // 2], noise_seed=np.array(seed), **{k: np.array(v) for k, v in kw.items()})
+
+    # DPM++ 2M (deterministic)
+    y_ref = run(S.DPMPP2MSampler(discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))
+    tr = []
+    y_or = osamp.dpmpp2m_sample(onet, z.clone(), cond, uc, steps, 6.5, tr)
+    check(f'DPMPP2M {steps} steps final latent', y_or, y_ref, 2e-4)
+    save('dpmpp2m_tiny_8', final=y_ref, mid=tr[steps // 2])
+
+
+SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim, 'flow_fixed': sec_flow_fixed,
+            'more_samplers': sec_more_samplers}
 
 if __name__ == '__main__':
     from make_golden_render import sec_render, sec_decoder, sec_render_presets   # noqa: E402

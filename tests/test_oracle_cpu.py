@@ -282,3 +282,33 @@ def test_oracle_multiview_conditioner_matches_goldens():
     img_c = {'img': synth_input('mvimg', (2, T + 1, 3, S, S), 7).clamp(-1, 1), 'c': torch.from_numpy(g['c'])}
     tok = ovit.dinov2_mv_plucker_forward(synth_vit_state_dict(sh, 0), img_c, int(g['heads']), n_cond_frames=T, size=S)
     assert tok.shape[:2] == (2, T) and rel_l2(tok[:, :, ::int(g['tok_stride'])], g['tokens']) < 1e-5
+
+
+def test_oracle_other_sgm_samplers_match_reference_goldens():
+    """r6: Heun (with / without churn), Euler-ancestral (two eta / s_noise settings), DPM++ 2S ancestral, DPM++ 2M (sampling.py:133-365)
+    through the reference's own classes (tests/golden/make_golden.py::sec_more_samplers), the stochastic ones with the reference's RNG
+    stream re-drawn from the stored seed."""
+    sd = _sd_from_manifest(golden('t23d_tiny'))
+    z = synth_input('z', (2, 12, 32, 32), 41)
+    cond = {'crossattn': synth_input('c', (2, 77, 768), 41), 'vector': synth_input('v', (2, 768), 41)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    net = lambda x, t, c: odit.t23d_forward(sd, x, t, c, 2)
+    g = golden('heun_tiny_8')
+    tr = []
+    y = osamp.edm_heun_sample(net, z.clone(), cond, uc, 8, 6.5, tr)
+    assert rel_l2(y, g['final']) < 1e-4 and rel_l2(tr[4], g['mid']) < 1e-4
+    g = golden('heun_tiny_8_churn')
+    torch.manual_seed(int(g['noise_seed']))
+    draws = {int(i): torch.randn(2, 12, 32, 32) for i in g['churned']}
+    y = osamp.edm_heun_sample(net, z.clone(), cond, uc, 8, 6.5, None, step_noise=lambda i: draws[i],
+                              s_churn=float(g['s_churn']), s_tmin=float(g['s_tmin']), s_tmax=float(g['s_tmax']), s_noise=float(g['s_noise']))
+    assert rel_l2(y, g['final']) < 1e-4
+    for tag, fn in (('euler_ancestral_tiny_8', osamp.euler_ancestral_sample), ('euler_ancestral_tiny_8_eta', osamp.euler_ancestral_sample),
+                    ('dpmpp2s_tiny_8', osamp.dpmpp2s_ancestral_sample)):
+        g = golden(tag)
+        torch.manual_seed(int(g['noise_seed']))
+        draws = [torch.randn(2, 12, 32, 32) for _ in range(8)]
+        y = fn(net, z.clone(), cond, uc, 8, 6.5, eta=float(g['eta']), s_noise=float(g['s_noise']), step_noise=lambda i: draws[i])
+        assert rel_l2(y, g['final']) < 1e-4, tag
+    g = golden('dpmpp2m_tiny_8')
+    assert rel_l2(osamp.dpmpp2m_sample(net, z.clone(), cond, uc, 8, 6.5), g['final']) < 1e-4

@@ -75,6 +75,55 @@ def test_edm_euler_with_churn_vs_reference_golden(hip_lib):
     assert rel_l2(y, y0) > 1e-2                                      # the injection is not a no-op
 
 
+def test_other_sgm_samplers_vs_reference_goldens(hip_lib):
+    """r6: HeunEDMSampler (with / without churn), EulerAncestralSampler (two eta / s_noise settings), DPMPP2SAncestralSampler,
+    DPMPP2MSampler (sampling.py:133-365) on the HIP path against the reference's own classes; the stochastic ones with the reference's RNG
+    stream re-drawn from the stored seed; through a bound DiscreteDenoiser, an opaque closure and network=."""
+    from ln3diff_amd.sgm import sampling as S
+    from ln3diff_amd.synth import synth_input
+    m = _tiny()
+    z = synth_input('z', (2, 12, 32, 32), 41).cuda()
+    cond = {'crossattn': synth_input('c', (2, 77, 768), 41).cuda()}
+    uc = {'crossattn': torch.zeros_like(cond['crossattn'])}
+    den = S.DiscreteDenoiser()
+    cfg = dict(num_steps=8, guider=S.VanillaCFG(6.5))
+    res = {}
+    g = golden('heun_tiny_8')
+    tr = []
+    y = S.HeunEDMSampler(**cfg)(den.bind(m), z.clone(), cond, uc, trace=tr)
+    res['heun'] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
+    y2 = S.HeunEDMSampler(**cfg)(den, z.clone(), cond, uc, network=m)
+    assert rel_l2(y2, y) < 1e-5
+    g = golden('heun_tiny_8_churn')
+    torch.manual_seed(int(g['noise_seed']))
+    draws = {int(i): torch.randn(2, 12, 32, 32) for i in g['churned']}
+    kw = dict(s_churn=float(g['s_churn']), s_tmin=float(g['s_tmin']), s_tmax=float(g['s_tmax']), s_noise=float(g['s_noise']))
+    y = S.HeunEDMSampler(**cfg, **kw)(den.bind(m), z.clone(), cond, uc, step_noise=lambda i: draws[i])
+    res['heun_churn'] = (rel_l2(y.cpu(), g['final']),)
+    for tag, cls in (('euler_ancestral_tiny_8', S.EulerAncestralSampler), ('euler_ancestral_tiny_8_eta', S.EulerAncestralSampler),
+                     ('dpmpp2s_tiny_8', S.DPMPP2SAncestralSampler)):
+        g = golden(tag)
+        torch.manual_seed(int(g['noise_seed']))
+        dr = [torch.randn(2, 12, 32, 32) for _ in range(8)]
+        tr = []
+
+        class Opaque:
+            def __call__(self, input, sigma, c):
+                return den(m, input, sigma, c)
+        y = cls(eta=float(g['eta']), s_noise=float(g['s_noise']), **cfg)(Opaque(), z.clone(), cond, uc, trace=tr, step_noise=lambda i: dr[i])
+        res[tag] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
+    g = golden('dpmpp2m_tiny_8')
+    tr = []
+    y = S.DPMPP2MSampler(**cfg)(den.bind(m), z.clone(), cond, uc, trace=tr)
+    res['dpmpp2m'] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
+    print('other samplers vs reference:', {k: tuple(round(v, 5) for v in e) for k, e in res.items()})
+    for k, e in res.items():
+        assert max(e) < 1e-2, (k, e)
+    # a device draw where no stream is given: finite, and different from the deterministic Euler result
+    y = S.EulerAncestralSampler(**cfg)(den.bind(m), z.clone(), cond, uc)
+    assert torch.isfinite(y).all()
+
+
 def test_config1_ditb2_ddpm50_vs_reference_golden(hip_lib):
     """BASELINE config 1: DiT-B/2, SpacedDiffusion('50').p_sample_loop, B=1 - the reference's CPU-runnable case."""
     from ln3diff_amd.dit.dit_trilatent import DiT_models
