@@ -5,7 +5,7 @@ Mirrors the reference's sgm surface for this path (same class names / call signa
   DiscreteDenoiser+EpsScaling sgm/modules/diffusionmodules/denoiser.py:45-78, denoiser_scaling.py:29-37
   VanillaCFG                 sgm/modules/diffusionmodules/guiders.py:24-42
   EulerEDMSampler            sgm/modules/diffusionmodules/sampling.py:82-130,211-215
-  HeunEDMSampler, EulerAncestralSampler, DPMPP2SAncestralSampler, DPMPP2MSampler (r6)   sampling.py:133-170, 218-365
+  HeunEDMSampler, EulerAncestralSampler, DPMPP2SAncestralSampler, DPMPP2MSampler, LinearMultistepSampler (r6)   sampling.py:133-365
 The sigma tables are built on the host in fp64/fp32 exactly like the reference; the per-step work is one
 network call on [uc ; c] (2B) with the c_in scale folded into the patch-embed kernel, and ONE fused
 elementwise kernel for denoiser-combine + CFG + Euler update (ln3d_edm_euler_step).  Context K/V are
@@ -329,7 +329,7 @@ _CAPTURE_STREAMS = {}
 # config of the reference's family resolves.  Host loops over the same device pieces as EulerEDMSampler's generic path: one closure call per
 # network evaluation (the CFG-doubled batch), every update ONE ln3d_lincomb launch with the guidance x_u + s (x_c - x_u) folded into its
 # coefficients (all of these updates are linear in x and the denoised halves).  sigma is one number per step (s_in * sigma in the reference),
-# so the step sizes are host scalars.  LinearMultistepSampler (scipy quadrature coefficients) is not built.
+# so the step sizes are host scalars.  LinearMultistepSampler computes its coefficients with scipy's quadrature like the reference.
 def _closure(denoiser, network):
     """(input, sigma, c) -> denoised [2B, ...]: the reference's lambda / BoundDenoiser as given, or DiscreteDenoiser + network= bound here."""
     if network is not None and isinstance(denoiser, DiscreteDenoiser):
@@ -486,6 +486,49 @@ class DPMPP2MSampler(_LoopSampler):
                 ops.lincomb(None, [x, du, dc, old[0], old[1]],
                             [m1, -m2 * m3 * (1.0 - sc), -m2 * m3 * sc, m2 * m4 * (1.0 - sc), m2 * m4 * sc], x)
             old = (du, dc)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
+
+def linear_multistep_coeff(order, t, i, j, epsrel=1e-4):
+    """sampling_utils.py:7-19 (scipy quadrature of the j-th Lagrange basis over [t_i, t_i+1], as the reference computes it)"""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def fn(tau):
+        prod = 1.0
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=epsrel)[0]
+
+
+class LinearMultistepSampler(_LoopSampler):
+    """sampling.py:172-208: Adams-Bashforth in sigma over the last `order` derivatives d = (x - denoised) / sigma; one evaluation per step.
+    Each d is one ln3d_lincomb (guidance folded in), the update another."""
+
+    def __init__(self, order=4, **kw):
+        super().__init__(**kw)
+        self.order = int(order)
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, **_):
+        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        sig_np = np.asarray(self.discretization(n, device="cpu"), dtype=np.float32)     # the reference's fp32 sigma table (sigmas.cpu().numpy())
+        ds = []
+        for i in range(n):
+            du, dc = self._den(call, x, sigmas[i], cond, uc)
+            d = torch.empty_like(x) if len(ds) < self.order else ds.pop(0)
+            inv = 1.0 / sigmas[i]
+            ops.lincomb(None, [x, du, dc], [inv, -inv * (1.0 - sc), -inv * sc], d)
+            ds.append(d)
+            cur = min(i + 1, self.order)
+            coeffs = [linear_multistep_coeff(cur, sig_np, i, j) for j in range(cur)]
+            ops.lincomb(x, list(reversed(ds))[:cur], coeffs, x)
             if trace is not None:
                 trace.append(x.clone())
         return x

@@ -217,6 +217,45 @@ def dpmpp2m_sample(net, z, cond, uc, num_steps=10, scale=6.5, trace=None):
     return x
 
 
+def linear_multistep_coeff(order, t, i, j, epsrel=1e-4):
+    """sampling_utils.linear_multistep_coeff (sampling_utils.py:7-19): the integral over [t_i, t_i+1] of the j-th Lagrange basis polynomial
+    through the last `order` sigmas (scipy quadrature, like the reference)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def fn(tau):
+        prod = 1.0
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=epsrel)[0]
+
+
+def linear_multistep_sample(net, z, cond, uc, num_steps=10, scale=6.5, order=4, trace=None):
+    """LinearMultistepSampler (sampling.py:172-208): Adams-Bashforth in sigma over the last `order` derivatives d = (x - denoised) / sigma."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    sig_np = sigmas.detach().cpu().numpy()
+    ds = []
+    for i in range(len(sigmas) - 1):
+        sigma = s_in * sigmas[i]
+        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
+        ds.append((x - den) / _bc(sigma, x))
+        if len(ds) > order:
+            ds.pop(0)
+        cur = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur, sig_np, i, j) for j in range(cur)]
+        x = x + sum(c * d for c, d in zip(coeffs, reversed(ds)))
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
 # --------------------------------------------------------- guided_diffusion DDPM
 def linear_betas(T=1000):
     scale = 1000 / T

@@ -448,6 +448,14 @@ def sec_more_samplers():
     check(f'DPMPP2M {steps} steps final latent', y_or, y_ref, 2e-4)
     save('dpmpp2m_tiny_8', final=y_ref, mid=tr[steps // 2])
 
+    # LinearMultistepSampler (deterministic, order 4 and 2)
+    for order in (4, 2):
+        y_ref = run(S.LinearMultistepSampler(order=order, discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))
+        tr = []
+        y_or = osamp.linear_multistep_sample(onet, z.clone(), cond, uc, steps, 6.5, order, tr)
+        check(f'LinearMultistep order {order} {steps} steps final latent', y_or, y_ref, 2e-4)
+        save(f'lms{order}_tiny_8', final=y_ref, mid=tr[steps // 2], order=np.array(order))
+
 
 SECTIONS = {'t23d': sec_t23d, 'samplers': sec_samplers, 'i23d': sec_i23d, 'ddim': sec_ddim, 'flow_fixed': sec_flow_fixed,
             'more_samplers': sec_more_samplers}

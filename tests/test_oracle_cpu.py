@@ -285,7 +285,7 @@ def test_oracle_multiview_conditioner_matches_goldens():
 
 
 def test_oracle_other_sgm_samplers_match_reference_goldens():
-    """r6: Heun (with / without churn), Euler-ancestral (two eta / s_noise settings), DPM++ 2S ancestral, DPM++ 2M (sampling.py:133-365)
+    """r6: Heun (with / without churn), Euler-ancestral (two eta / s_noise settings), DPM++ 2S ancestral, DPM++ 2M, linear multistep (sampling.py:133-365)
     through the reference's own classes (tests/golden/make_golden.py::sec_more_samplers), the stochastic ones with the reference's RNG
     stream re-drawn from the stored seed."""
     sd = _sd_from_manifest(golden('t23d_tiny'))
@@ -312,3 +312,6 @@ def test_oracle_other_sgm_samplers_match_reference_goldens():
         assert rel_l2(y, g['final']) < 1e-4, tag
     g = golden('dpmpp2m_tiny_8')
     assert rel_l2(osamp.dpmpp2m_sample(net, z.clone(), cond, uc, 8, 6.5), g['final']) < 1e-4
+    for order in (4, 2):
+        g = golden('lms%d_tiny_8' % order)
+        assert rel_l2(osamp.linear_multistep_sample(net, z.clone(), cond, uc, 8, 6.5, order), g['final']) < 1e-4, order

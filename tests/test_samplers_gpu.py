@@ -77,7 +77,7 @@ def test_edm_euler_with_churn_vs_reference_golden(hip_lib):
 
 def test_other_sgm_samplers_vs_reference_goldens(hip_lib):
     """r6: HeunEDMSampler (with / without churn), EulerAncestralSampler (two eta / s_noise settings), DPMPP2SAncestralSampler,
-    DPMPP2MSampler (sampling.py:133-365) on the HIP path against the reference's own classes; the stochastic ones with the reference's RNG
+    DPMPP2MSampler, LinearMultistepSampler (sampling.py:133-365) on the HIP path against the reference's own classes; the stochastic ones with the reference's RNG
     stream re-drawn from the stored seed; through a bound DiscreteDenoiser, an opaque closure and network=."""
     from ln3diff_amd.sgm import sampling as S
     from ln3diff_amd.synth import synth_input
@@ -116,6 +116,11 @@ def test_other_sgm_samplers_vs_reference_goldens(hip_lib):
     tr = []
     y = S.DPMPP2MSampler(**cfg)(den.bind(m), z.clone(), cond, uc, trace=tr)
     res['dpmpp2m'] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
+    for order in (4, 2):
+        g = golden('lms%d_tiny_8' % order)
+        tr = []
+        y = S.LinearMultistepSampler(order=order, **cfg)(den.bind(m), z.clone(), cond, uc, trace=tr)
+        res['lms%d' % order] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
     print('other samplers vs reference:', {k: tuple(round(v, 5) for v in e) for k, e in res.items()})
     for k, e in res.items():
         assert max(e) < 1e-2, (k, e)
