@@ -312,6 +312,10 @@ def render_probe(dev, dec, res=256, V=4, iters=5):
         rec.update({"achieved": round(iss["valu_insts"] / (ms * 1e-3) / 1e9, 1), "peak": round(1024 * clock_ghz / 4, 1),
                     "frac": round(iss["valu_busy_frac"], 4), "valu_insts_per_ray": round(iss["valu_insts"] / (V * res * res), 0),
                     "mfma_busy_frac": round(iss["mfma_busy_frac"], 4), "lds_busy_frac": round(iss["lds_busy_frac"], 4),
+                    # r6: the other throughput term of the kernel (profiles/r6_render_abl.log: without the texel loads it is 30 % faster) - every
+                    # vector-memory read of the marcher is a wave64 dwordx4 = 1 KB through the CU's L1 path, taken at 64 B per clock
+                    "l1_path_busy_est": (round(ent["counters"]["SQ_INSTS_VMEM_RD"] * 16.0 / (iss["cycles_per_launch"] * 256.0), 4)
+                                         if ent.get("counters", {}).get("SQ_INSTS_VMEM_RD") else None),
                     "issue_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (tools/r6_pmc.sh; "
                                     "quad-cycle counters x 4, 1024 SIMDs); frac = VALU-busy SIMD cycles / elapsed SIMD cycles"})
     else:
