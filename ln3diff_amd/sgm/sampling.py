@@ -68,6 +68,23 @@ class VanillaCFG:
         return torch.cat([x] * 2), torch.cat([s] * 2), c_out
 
 
+class IdentityGuider:
+    """guiders.py:45-57 (the reference's default when no guider_config is given): no guidance, the batch is not doubled."""
+    scale = None
+
+    def prepare_inputs(self, x, s, c, uc):
+        return x, s, {k: c[k] for k in c}
+
+
+def _guided_terms(guider, den, B, coef):
+    """(tensors, coefficients) of coef * guider(denoised) for one ln3d_lincomb: VanillaCFG's x_u + s (x_c - x_u) as two weighted halves,
+    IdentityGuider's single batch as is."""
+    if getattr(guider, 'scale', None) is None:
+        return [den], [coef]
+    sc = float(guider.scale)
+    return [den[:B], den[B:]], [coef * (1.0 - sc), coef * sc]
+
+
 class DiscreteDenoiser:
     """EpsScaling + index quantisation; `sigmas` is the ascending 1000-entry table (denoiser.py:45-78, denoiser_scaling.py:29-37)."""
 
@@ -205,8 +222,9 @@ class EulerEDMSampler:
             den, net = denoiser, network
         else:
             den, net = _find_pair(denoiser)
-        if net is None:
-            return self._generic(denoiser, x, cond, uc, num_steps, trace, step_noise)
+        if net is None or isinstance(self.guider, IdentityGuider):        # the fused loop is the CFG-doubled schedule
+            gen = denoiser if net is None else (lambda x_, s_, c_: den(net, x_, s_, c_))
+            return self._generic(gen, x, cond, uc, num_steps, trace, step_noise)
         uc = cond if uc is None else uc
         return self._fast(den, net, x, cond, uc, num_steps, trace, step_noise)
 
@@ -226,7 +244,6 @@ class EulerEDMSampler:
         x = (x * float(torch.sqrt(1.0 + sigmas[0] ** 2.0))).contiguous()
         B = x.shape[0]
         s_in = x.new_ones([B])
-        sc = float(self.guider.scale)
         for i in range(n):
             sig, nxt = float(sigmas[i]), float(sigmas[i + 1])
             if gammas[i] > 0:
@@ -234,7 +251,8 @@ class EulerEDMSampler:
             den = denoiser(*self.guider.prepare_inputs(x, s_in * sig, cond, uc)).contiguous().float()
             # guider + to_d + euler_step in one combination: x + dt/sigma * (x - (x_u + s (x_c - x_u)))
             r = (nxt - sig) / sig
-            ops.lincomb(x, [x, den[:B], den[B:]], [r, -r * (1.0 - sc), -r * sc], x)
+            dk, dcf = _guided_terms(self.guider, den, B, -r)
+            ops.lincomb(x, [x] + dk, [r] + dcf, x)
             if trace is not None:
                 trace.append(x.clone())
         return x
@@ -347,15 +365,16 @@ class _LoopSampler:
         n = self.num_steps if num_steps is None else num_steps
         sigmas = [float(v) for v in self.discretization(n, device="cpu")]
         x = (x * float((1.0 + sigmas[0] ** 2.0) ** 0.5)).contiguous()
-        return n, sigmas, _closure(denoiser, network), (cond if uc is None else uc), x, x.shape[0], float(self.guider.scale)
+        return n, sigmas, _closure(denoiser, network), (cond if uc is None else uc), x
 
     def _den(self, call, x, sig, cond, uc, keep=False):
-        """the two halves (x_u, x_c) of the denoised CFG batch at noise level sig; keep = they must survive the next network call"""
+        """the denoised batch at noise level sig as the guider laid it out ([uc ; c] for VanillaCFG); keep = it must survive the next call"""
         B = x.shape[0]
         out = call(*self.guider.prepare_inputs(x, x.new_ones([B]) * sig, cond, uc)).contiguous().float()
-        if keep:
-            out = out.clone()
-        return out[:B], out[B:]
+        return out.clone() if keep else out
+
+    def _g(self, den, x, coef):
+        return _guided_terms(self.guider, den, x.shape[0], coef)
 
     @staticmethod
     def _noise(x, i, step_noise):
@@ -383,22 +402,25 @@ class HeunEDMSampler(EulerEDMSampler):
         call = _closure(denoiser, network)
         uc = cond if uc is None else uc
         x = (x * float((1.0 + sigmas[0] ** 2.0) ** 0.5)).contiguous()
-        B, sc = x.shape[0], float(self.guider.scale)
+        B = x.shape[0]
         xe = torch.empty_like(x)
         den = _LoopSampler._den
         for i in range(n):
             sig, nxt = sigmas[i], sigmas[i + 1]
             if gammas[i] > 0:
                 sig = self._churn(x, sig, gammas[i], i, step_noise)
-            du, dc = den(self, call, x, sig, cond, uc, keep=True)
+            d1 = den(self, call, x, sig, cond, uc, keep=True)
             r = (nxt - sig) / sig
-            ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], xe)                       # the Euler step
+            k1, c1 = _guided_terms(self.guider, d1, B, -r)
+            ops.lincomb(x, [x] + k1, [r] + c1, xe)                                               # the Euler step
             if nxt < 1e-14:
                 x.copy_(xe)
             else:                                                                                # x + dt ((x - D) / sig + (x_e - D2) / nxt) / 2
-                d2u, d2c = den(self, call, xe, nxt, cond, uc)
+                d2 = den(self, call, xe, nxt, cond, uc)
                 a, b = (nxt - sig) / (2.0 * sig), (nxt - sig) / (2.0 * nxt)
-                ops.lincomb(x, [x, du, dc, xe, d2u, d2c], [a, -a * (1.0 - sc), -a * sc, b, -b * (1.0 - sc), -b * sc], x)
+                k1, c1 = _guided_terms(self.guider, d1, B, -a)
+                k2, c2 = _guided_terms(self.guider, d2, B, -b)
+                ops.lincomb(x, [x] + k1 + [xe] + k2, [a] + c1 + [b] + c2, x)
             if trace is not None:
                 trace.append(x.clone())
         return x
@@ -418,13 +440,14 @@ class EulerAncestralSampler(_LoopSampler):
 
     @torch.no_grad()
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
-        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        n, sigmas, call, uc, x = self._setup(denoiser, x, cond, uc, num_steps, network)
         for i in range(n):
             sig, nxt = sigmas[i], sigmas[i + 1]
             down, up = _ancestral(sig, nxt, self.eta)
-            du, dc = self._den(call, x, sig, cond, uc)
+            d1 = self._den(call, x, sig, cond, uc)
             r = (down - sig) / sig
-            ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], x)
+            k1, c1 = self._g(d1, x, -r)
+            ops.lincomb(x, [x] + k1, [r] + c1, x)
             self._ancestral_noise(x, i, nxt, up, step_noise)
             if trace is not None:
                 trace.append(x.clone())
@@ -437,24 +460,27 @@ class DPMPP2SAncestralSampler(EulerAncestralSampler):
 
     @torch.no_grad()
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, step_noise=None):
-        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        n, sigmas, call, uc, x = self._setup(denoiser, x, cond, uc, num_steps, network)
         x2 = torch.empty_like(x)
         for i in range(n):
             sig, nxt = sigmas[i], sigmas[i + 1]
             down, up = _ancestral(sig, nxt, self.eta)
-            du, dc = self._den(call, x, sig, cond, uc)
+            d1 = self._den(call, x, sig, cond, uc)
             if down < 1e-14:
                 r = (down - sig) / sig
-                ops.lincomb(x, [x, du, dc], [r, -r * (1.0 - sc), -r * sc], x)
+                k1, c1 = self._g(d1, x, -r)
+                ops.lincomb(x, [x] + k1, [r] + c1, x)
             else:
                 t, t_next = -math.log(sig), -math.log(down)
                 h = t_next - t
                 sm = t + 0.5 * h
                 m1, m2 = math.exp(-sm) / math.exp(-t), math.expm1(-0.5 * h)
                 m3, m4 = math.exp(-t_next) / math.exp(-t), math.expm1(-h)
-                ops.lincomb(None, [x, du, dc], [m1, -m2 * (1.0 - sc), -m2 * sc], x2)               # x2 = m1 x - m2 D
-                d2u, d2c = self._den(call, x2, math.exp(-sm), cond, uc)
-                ops.lincomb(None, [x, d2u, d2c], [m3, -m4 * (1.0 - sc), -m4 * sc], x)              # x = m3 x - m4 D2
+                k1, c1 = self._g(d1, x, -m2)
+                ops.lincomb(None, [x] + k1, [m1] + c1, x2)                                         # x2 = m1 x - m2 D
+                d2 = self._den(call, x2, math.exp(-sm), cond, uc)
+                k2, c2 = self._g(d2, x, -m4)
+                ops.lincomb(None, [x] + k2, [m3] + c2, x)                                          # x = m3 x - m4 D2
             self._ancestral_noise(x, i, nxt, up, step_noise)
             if trace is not None:
                 trace.append(x.clone())
@@ -467,11 +493,11 @@ class DPMPP2MSampler(_LoopSampler):
 
     @torch.no_grad()
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, **_):
-        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        n, sigmas, call, uc, x = self._setup(denoiser, x, cond, uc, num_steps, network)
         old = None
         for i in range(n):
             sig, nxt = sigmas[i], sigmas[i + 1]
-            du, dc = self._den(call, x, sig, cond, uc, keep=True)
+            d1 = self._den(call, x, sig, cond, uc, keep=True)
             t = -math.log(sig)
             if nxt < 1e-14:                                   # t_next = +inf: mult1 = 0, mult2 = expm1(-inf) = -1
                 m1, m2, h = 0.0, -1.0, float('inf')
@@ -479,13 +505,15 @@ class DPMPP2MSampler(_LoopSampler):
                 h = -math.log(nxt) - t
                 m1, m2 = nxt / sig, math.expm1(-h)
             if old is None or nxt < 1e-14:
-                ops.lincomb(None, [x, du, dc], [m1, -m2 * (1.0 - sc), -m2 * sc], x)
+                k1, c1 = self._g(d1, x, -m2)
+                ops.lincomb(None, [x] + k1, [m1] + c1, x)
             else:
                 r = (t + math.log(sigmas[i - 1])) / h
                 m3, m4 = 1.0 + 1.0 / (2.0 * r), 1.0 / (2.0 * r)
-                ops.lincomb(None, [x, du, dc, old[0], old[1]],
-                            [m1, -m2 * m3 * (1.0 - sc), -m2 * m3 * sc, m2 * m4 * (1.0 - sc), m2 * m4 * sc], x)
-            old = (du, dc)
+                k1, c1 = self._g(d1, x, -m2 * m3)
+                k0, c0 = self._g(old, x, m2 * m4)
+                ops.lincomb(None, [x] + k1 + k0, [m1] + c1 + c0, x)
+            old = d1
             if trace is not None:
                 trace.append(x.clone())
         return x
@@ -517,14 +545,15 @@ class LinearMultistepSampler(_LoopSampler):
 
     @torch.no_grad()
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, *, network=None, trace=None, **_):
-        n, sigmas, call, uc, x, B, sc = self._setup(denoiser, x, cond, uc, num_steps, network)
+        n, sigmas, call, uc, x = self._setup(denoiser, x, cond, uc, num_steps, network)
         sig_np = np.asarray(self.discretization(n, device="cpu"), dtype=np.float32)     # the reference's fp32 sigma table (sigmas.cpu().numpy())
         ds = []
         for i in range(n):
-            du, dc = self._den(call, x, sigmas[i], cond, uc)
+            d1 = self._den(call, x, sigmas[i], cond, uc)
             d = torch.empty_like(x) if len(ds) < self.order else ds.pop(0)
             inv = 1.0 / sigmas[i]
-            ops.lincomb(None, [x, du, dc], [inv, -inv * (1.0 - sc), -inv * sc], d)
+            k1, c1 = self._g(d1, x, -inv)
+            ops.lincomb(None, [x] + k1, [inv] + c1, d)
             ds.append(d)
             cur = min(i + 1, self.order)
             coeffs = [linear_multistep_coeff(cur, sig_np, i, j) for j in range(cur)]

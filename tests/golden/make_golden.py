@@ -448,6 +448,17 @@ def sec_more_samplers():
     check(f'DPMPP2M {steps} steps final latent', y_or, y_ref, 2e-4)
     save('dpmpp2m_tiny_8', final=y_ref, mid=tr[steps // 2])
 
+    # IdentityGuider (the reference's default without a guider_config: no guidance, the batch is not doubled) under Euler and Heun.  The oracle
+    # has one guider: scale 1 with uc = c is the same arithmetic up to the rounding of x_u + (x_c - x_u)
+    for name, cls, fn in (('euler_identity_tiny_8', S.EulerEDMSampler, osamp.edm_euler_sample), ('heun_identity_tiny_8', S.HeunEDMSampler, osamp.edm_heun_sample)):
+        sampler = cls(discretization_config=dc, num_steps=steps, device='cpu')
+        assert type(sampler.guider).__name__ == 'IdentityGuider'
+        n0 = len(calls)
+        y_ref = run(sampler)
+        y_or = fn(onet, z.clone(), cond, cond, steps, 1.0)
+        check(f'{cls.__name__} with IdentityGuider final latent', y_or, y_ref, 2e-4)
+        save(name, final=y_ref, net_calls=np.array(len(calls) - n0))
+
     # LinearMultistepSampler (deterministic, order 4 and 2)
     for order in (4, 2):
         y_ref = run(S.LinearMultistepSampler(order=order, discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))

@@ -121,6 +121,20 @@ def test_other_sgm_samplers_vs_reference_goldens(hip_lib):
         tr = []
         y = S.LinearMultistepSampler(order=order, **cfg)(den.bind(m), z.clone(), cond, uc, trace=tr)
         res['lms%d' % order] = (rel_l2(y.cpu(), g['final']), rel_l2(tr[4].cpu(), g['mid']))
+    # IdentityGuider (the reference's default guider): B rows through the network instead of 2B, the same loops
+    for tag, cls in (('euler_identity_tiny_8', S.EulerEDMSampler), ('heun_identity_tiny_8', S.HeunEDMSampler)):
+        g = golden(tag)
+        seen = []
+
+        class Count:
+            def __call__(self, input, sigma, c):
+                seen.append(input.shape[0])
+                return den(m, input, sigma, c)
+        y = cls(num_steps=8, guider=S.IdentityGuider())(Count(), z.clone(), cond, None)
+        assert seen and all(b == 2 for b in seen) and len(seen) == int(g['net_calls'])
+        res[tag] = (rel_l2(y.cpu(), g['final']),)
+    y = S.EulerEDMSampler(num_steps=8, guider=S.IdentityGuider())(den.bind(m), z.clone(), cond, None)      # a bound pair: still the un-doubled loop
+    assert rel_l2(y.cpu(), golden('euler_identity_tiny_8')['final']) < 1e-2
     print('other samplers vs reference:', {k: tuple(round(v, 5) for v in e) for k, e in res.items()})
     for k, e in res.items():
         assert max(e) < 1e-2, (k, e)
