@@ -347,7 +347,7 @@ _CAPTURE_STREAMS = {}
 # config of the reference's family resolves.  Host loops over the same device pieces as EulerEDMSampler's generic path: one closure call per
 # network evaluation (the CFG-doubled batch), every update ONE ln3d_lincomb launch with the guidance x_u + s (x_c - x_u) folded into its
 # coefficients (all of these updates are linear in x and the denoised halves).  sigma is one number per step (s_in * sigma in the reference),
-# so the step sizes are host scalars.  LinearMultistepSampler computes its coefficients with scipy's quadrature like the reference.
+# so the step sizes are host scalars.  LinearMultistepSampler's weights are the closed-form integrals of the Lagrange basis (the reference integrates the same polynomials numerically).
 def _closure(denoiser, network):
     """(input, sigma, c) -> denoised [2B, ...]: the reference's lambda / BoundDenoiser as given, or DiscreteDenoiser + network= bound here."""
     if network is not None and isinstance(denoiser, DiscreteDenoiser):
@@ -519,20 +519,19 @@ class DPMPP2MSampler(_LoopSampler):
         return x
 
 
-def linear_multistep_coeff(order, t, i, j, epsrel=1e-4):
-    """sampling_utils.py:7-19 (scipy quadrature of the j-th Lagrange basis over [t_i, t_i+1], as the reference computes it)"""
-    from scipy import integrate
+def linear_multistep_coeff(order, t, i, j):
+    """The Adams-Bashforth weight of derivative j steps back for the step t[i] -> t[i + 1]: the integral over that interval of the Lagrange
+    basis polynomial through the last `order` nodes t[i], t[i - 1], ... (sampling_utils.py:7-19 evaluates the same integral with scipy's
+    adaptive quadrature at epsrel 1e-4; the integrand is a polynomial of degree < order, so the closed form below is that value exactly)."""
     if order - 1 > i:
         raise ValueError(f"Order {order} too high for step {i}")
-
-    def fn(tau):
-        prod = 1.0
-        for k in range(order):
-            if j == k:
-                continue
-            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
-        return prod
-    return integrate.quad(fn, t[i], t[i + 1], epsrel=epsrel)[0]
+    nodes = [float(t[i - k]) for k in range(order)]
+    basis = np.poly1d([1.0])
+    for k in range(order):
+        if k != j:
+            basis = basis * np.poly1d([1.0, -nodes[k]]) / (nodes[j] - nodes[k])
+    prim = basis.integ()
+    return float(prim(float(t[i + 1])) - prim(float(t[i])))
 
 
 class LinearMultistepSampler(_LoopSampler):

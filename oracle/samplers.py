@@ -217,21 +217,19 @@ def dpmpp2m_sample(net, z, cond, uc, num_steps=10, scale=6.5, trace=None):
     return x
 
 
-def linear_multistep_coeff(order, t, i, j, epsrel=1e-4):
-    """sampling_utils.linear_multistep_coeff (sampling_utils.py:7-19): the integral over [t_i, t_i+1] of the j-th Lagrange basis polynomial
-    through the last `order` sigmas (scipy quadrature, like the reference)."""
-    from scipy import integrate
+def linear_multistep_coeff(order, t, i, j):
+    """The Adams-Bashforth weight of derivative j steps back for the step t[i] -> t[i + 1]: the integral over that interval of the Lagrange
+    basis polynomial through the last `order` nodes t[i], t[i - 1], ... (sampling_utils.py:7-19 evaluates the same integral with scipy's
+    adaptive quadrature at epsrel 1e-4; the integrand is a polynomial of degree < order, so the closed form below is that value exactly)."""
     if order - 1 > i:
         raise ValueError(f"Order {order} too high for step {i}")
-
-    def fn(tau):
-        prod = 1.0
-        for k in range(order):
-            if j == k:
-                continue
-            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
-        return prod
-    return integrate.quad(fn, t[i], t[i + 1], epsrel=epsrel)[0]
+    nodes = [float(t[i - k]) for k in range(order)]
+    basis = np.poly1d([1.0])
+    for k in range(order):
+        if k != j:
+            basis = basis * np.poly1d([1.0, -nodes[k]]) / (nodes[j] - nodes[k])
+    prim = basis.integ()
+    return float(prim(float(t[i + 1])) - prim(float(t[i])))
 
 
 def linear_multistep_sample(net, z, cond, uc, num_steps=10, scale=6.5, order=4, trace=None):

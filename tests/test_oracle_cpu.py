@@ -317,3 +317,24 @@ def test_oracle_other_sgm_samplers_match_reference_goldens():
     for order in (4, 2):
         g = golden('lms%d_tiny_8' % order)
         assert rel_l2(osamp.linear_multistep_sample(net, z.clone(), cond, uc, 8, 6.5, order), g['final']) < 1e-4, order
+
+
+def test_linear_multistep_weights_equal_the_reference_quadrature():
+    """The closed-form Lagrange integrals (oracle and product) against scipy's adaptive quadrature of the same integrand, which is how
+    sampling_utils.py:7-19 computes them; every (order, step, j) of an 8- and a 50-step LegacyDDPM schedule."""
+    from scipy import integrate
+    from ln3diff_amd.sgm.sampling import linear_multistep_coeff as prod_coeff
+    for n in (8, 50):
+        t = osamp.legacy_ddpm_sigmas(n).numpy()
+        for i in range(n):
+            for order in range(1, min(i + 1, 4) + 1):
+                for j in range(order):
+                    def fn(tau):
+                        prod = 1.0
+                        for k in range(order):
+                            if j != k:
+                                prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+                        return prod
+                    ref = integrate.quad(fn, t[i], t[i + 1], epsrel=1e-4)[0]
+                    a, b = osamp.linear_multistep_coeff(order, t, i, j), prod_coeff(order, t, i, j)
+                    assert abs(a - ref) <= 1e-6 * max(1.0, abs(ref)) and a == b, (n, i, order, j, a, b, ref)
