@@ -2,7 +2,7 @@
 
 Mirrors the reference's sgm surface for this path (same class names / call signatures):
   LegacyDDPMDiscretization   sgm/modules/diffusionmodules/discretizer.py:42-69
-  DiscreteDenoiser+EpsScaling sgm/modules/diffusionmodules/denoiser.py:45-78, denoiser_scaling.py:29-37
+  Denoiser / DiscreteDenoiser + EpsScaling / VScaling / VScalingWithEDMcNoise / EDMScaling   sgm/modules/diffusionmodules/denoiser.py:13-78, denoiser_scaling.py:14-59
   VanillaCFG                 sgm/modules/diffusionmodules/guiders.py:24-42
   EulerEDMSampler            sgm/modules/diffusionmodules/sampling.py:82-130,211-215
   HeunEDMSampler, EulerAncestralSampler, DPMPP2SAncestralSampler, DPMPP2MSampler, LinearMultistepSampler (r6)   sampling.py:133-365
@@ -85,13 +85,97 @@ def _guided_terms(guider, den, B, coef):
     return [den[:B], den[B:]], [coef * (1.0 - sc), coef * sc]
 
 
-class DiscreteDenoiser:
-    """EpsScaling + index quantisation; `sigmas` is the ascending 1000-entry table (denoiser.py:45-78, denoiser_scaling.py:29-37)."""
+def _f32(v):
+    return torch.tensor(float(v), dtype=torch.float32)
 
-    def __init__(self, num_idx=1000, discretization=None):
+
+class EpsScaling:
+    """denoiser_scaling.py:29-37 (the released configuration): c_skip 1, c_out -sigma, c_in 1 / sqrt(sigma^2 + 1), c_noise sigma - evaluated in
+    fp32 like the reference's tensors."""
+
+    def __call__(self, sigma):
+        s = _f32(sigma)
+        return 1.0, float(-s), float(1.0 / (s ** 2 + 1.0) ** 0.5), float(s)
+
+
+class VScaling:
+    """denoiser_scaling.py:40-48"""
+
+    def __call__(self, sigma):
+        s = _f32(sigma)
+        return float(1.0 / (s ** 2 + 1.0)), float(-s / (s ** 2 + 1.0) ** 0.5), float(1.0 / (s ** 2 + 1.0) ** 0.5), float(s)
+
+
+class VScalingWithEDMcNoise(VScaling):
+    """denoiser_scaling.py:51-59"""
+
+    def __call__(self, sigma):
+        c_skip, c_out, c_in, _ = super().__call__(sigma)
+        return c_skip, c_out, c_in, float(0.25 * _f32(sigma).log())
+
+
+class EDMScaling:
+    """denoiser_scaling.py:14-26"""
+
+    def __init__(self, sigma_data=0.5):
+        self.sigma_data = float(sigma_data)
+
+    def __call__(self, sigma):
+        s, d = _f32(sigma), _f32(self.sigma_data)
+        return (float(d ** 2 / (s ** 2 + d ** 2)), float(s * d / (s ** 2 + d ** 2) ** 0.5), float(1 / (s ** 2 + d ** 2) ** 0.5),
+                float(0.25 * s.log()))
+
+
+class Denoiser:
+    """denoiser.py:13-42: c_skip * input + c_out * network(c_in * input, c_noise, cond) with the scaling's four factors; no quantisation
+    (the network sees c_noise as a float).  One sigma per call is assumed to be shared by the batch (every sampler of this path)."""
+
+    def __init__(self, scaling=None):
+        self.scaling = scaling or EpsScaling()
+
+    def quantize(self, sigma):
+        """(sigma the scalings are evaluated at, None): the continuous denoiser passes sigma through"""
+        return float(sigma), None
+
+    def noise_label(self, c_noise):
+        return float(c_noise)
+
+    @torch.no_grad()
+    def __call__(self, network, input, sigma, cond, **additional_model_inputs):
+        """`network` is a ln3diff_amd DiT (c_in rides on its patch-embed kernel) or any callable (x, t, cond) -> output on the device."""
+        sig, _ = self.quantize(float(sigma.reshape(-1)[0]))
+        c_skip, c_out, c_in, c_noise = self.scaling(sig)
+        n = input.shape[0]
+        t = torch.full((n,), self.noise_label(c_noise), device=input.device, dtype=torch.float32)
+        if hasattr(network, 'prepare_context'):
+            eps = network(input, t, context=cond, in_scale=torch.full((n,), c_in, device=input.device, dtype=torch.float32),
+                          **additional_model_inputs)
+        else:
+            eps = network(input * c_in, t, cond, **additional_model_inputs)
+        out = torch.empty_like(input, dtype=torch.float32)
+        xin = input.contiguous().float()
+        if c_skip == 1.0:
+            ops.lincomb(xin, [eps.contiguous().float()], [c_out], out)
+        else:
+            ops.lincomb(None, [xin, eps.contiguous().float()], [c_skip, c_out], out)
+        return out
+
+    def bind(self, network, **additional_model_inputs):
+        """The closure DiffusionEngineLSGM.sample hands to its sampler (sgm_DiffusionEngine.py:401-403):
+        `lambda input, sigma, c: self.denoiser(self.model, input, sigma, c, **kwargs)` - as an object the sampler can look into."""
+        return BoundDenoiser(self, network, **additional_model_inputs)
+
+
+class DiscreteDenoiser(Denoiser):
+    """denoiser.py:45-78: sigma snapped to the ascending 1000-entry table before the scalings are evaluated, c_noise replaced by its table index
+    (quantize_c_noise).  With EpsScaling (the released configuration) the network's timestep is the index of the snapped sigma."""
+
+    def __init__(self, num_idx=1000, discretization=None, scaling=None, quantize_c_noise=True):
+        super().__init__(scaling)
         self.discretization = discretization or LegacyDDPMDiscretization()
         self.sigmas = self.discretization(num_idx, do_append_zero=False, flip=True)
         self.num_idx = num_idx
+        self.quantize_c_noise = bool(quantize_c_noise)
 
     def sigma_to_idx(self, sigma):
         return int((self.sigmas - float(sigma)).abs().argmin())
@@ -101,29 +185,13 @@ class DiscreteDenoiser:
         s = float(self.sigmas[i])
         return s, self.sigma_to_idx(s)
 
-    @torch.no_grad()
-    def __call__(self, network, input, sigma, cond, **additional_model_inputs):
-        """Denoiser.forward (denoiser.py:24-44) with EpsScaling: network(input * c_in, idx(sigma), cond) * (-sigma_q) + input.
-        `network` is a ln3diff_amd DiT (c_in rides on its patch-embed kernel) or any callable (x, t, cond) -> eps on the device.
-        One sigma per call is assumed to be shared by the batch (every sampler of this path), like the table lookup it feeds."""
-        sig, idx = self.quantize(float(sigma.reshape(-1)[0]))
-        c_in = float(1.0 / (torch.tensor(sig, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
-        n = input.shape[0]
-        t = torch.full((n,), float(idx), device=input.device, dtype=torch.float32)
-        if hasattr(network, 'prepare_context'):
-            eps = network(input, t, context=cond, in_scale=torch.full((n,), c_in, device=input.device, dtype=torch.float32),
-                          **additional_model_inputs)
-        else:
-            eps = network(input * c_in, t, cond, **additional_model_inputs)
-        out = torch.empty_like(input, dtype=torch.float32)
-        ops.lincomb(input.contiguous().float(), [eps.contiguous().float()], [-sig], out)       # c_skip = 1, c_out = -sigma
-        return out
+    def noise_label(self, c_noise):
+        return float(self.sigma_to_idx(c_noise)) if self.quantize_c_noise else float(c_noise)
 
-    def bind(self, network, **additional_model_inputs):
-        """The closure DiffusionEngineLSGM.sample hands to its sampler (sgm_DiffusionEngine.py:401-403):
-        `lambda input, sigma, c: self.denoiser(self.model, input, sigma, c, **kwargs)` - as an object the sampler can look into."""
-        return BoundDenoiser(self, network, **additional_model_inputs)
-
+    @property
+    def fused_ok(self):
+        """the fused network loop of EulerEDMSampler bakes EpsScaling + the index timestep in"""
+        return type(self.scaling) is EpsScaling and self.quantize_c_noise
 
 class BoundDenoiser:
     def __init__(self, denoiser, network, **additional_model_inputs):
@@ -218,11 +286,11 @@ class EulerEDMSampler:
         closure is recognisably this package's DiscreteDenoiser over one of its networks (`DiscreteDenoiser.bind(network)`, the
         reference's own lambda over an engine, or `network=` with a DiscreteDenoiser).  Any other callable runs the generic loop
         with the same arithmetic, one closure call per step."""
-        if network is not None and isinstance(denoiser, DiscreteDenoiser):
+        if network is not None and isinstance(denoiser, Denoiser):
             den, net = denoiser, network
         else:
             den, net = _find_pair(denoiser)
-        if net is None or isinstance(self.guider, IdentityGuider):        # the fused loop is the CFG-doubled schedule
+        if net is None or isinstance(self.guider, IdentityGuider) or not getattr(den, 'fused_ok', False):   # the fused loop: CFG-doubled, EpsScaling
             gen = denoiser if net is None else (lambda x_, s_, c_: den(net, x_, s_, c_))
             return self._generic(gen, x, cond, uc, num_steps, trace, step_noise)
         uc = cond if uc is None else uc
@@ -350,7 +418,7 @@ _CAPTURE_STREAMS = {}
 # so the step sizes are host scalars.  LinearMultistepSampler's weights are the closed-form integrals of the Lagrange basis (the reference integrates the same polynomials numerically).
 def _closure(denoiser, network):
     """(input, sigma, c) -> denoised [2B, ...]: the reference's lambda / BoundDenoiser as given, or DiscreteDenoiser + network= bound here."""
-    if network is not None and isinstance(denoiser, DiscreteDenoiser):
+    if network is not None and isinstance(denoiser, Denoiser):
         return lambda x, s, c: denoiser(network, x, s, c)
     return denoiser
 

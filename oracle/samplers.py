@@ -52,24 +52,37 @@ def sigma_to_idx(sigma, table):
     return (sigma[None, :] - table[:, None]).abs().argmin(dim=0)
 
 
-def edm_denoise_cfg(net, x, sigma, cond, uc, scale, table):
-    """VanillaCFG.prepare_inputs ([uc, c] order) -> DiscreteDenoiser(EpsScaling) -> CFG."""
-    B = x.shape[0]
+def denoiser_scaling(kind, sb, sigma_data=0.5):
+    """denoiser_scaling.py:14-59: (c_skip, c_out, c_in, c_noise) of EpsScaling / VScaling / VScalingWithEDMcNoise / EDMScaling at sigma sb"""
+    if kind == 'eps':
+        return torch.ones_like(sb), -sb, 1 / (sb ** 2 + 1.0) ** 0.5, sb.clone()
+    if kind in ('v', 'v_edm'):
+        return 1.0 / (sb ** 2 + 1.0), -sb / (sb ** 2 + 1.0) ** 0.5, 1.0 / (sb ** 2 + 1.0) ** 0.5, (sb.clone() if kind == 'v' else 0.25 * sb.log())
+    if kind == 'edm':
+        d = sigma_data
+        return d ** 2 / (sb ** 2 + d ** 2), sb * d / (sb ** 2 + d ** 2) ** 0.5, 1 / (sb ** 2 + d ** 2) ** 0.5, 0.25 * sb.log()
+    raise ValueError(kind)
+
+
+def edm_denoise_cfg(net, x, sigma, cond, uc, scale, table, scaling='eps', discrete=True, quantize_c_noise=True):
+    """VanillaCFG.prepare_inputs ([uc, c] order) -> Denoiser / DiscreteDenoiser.forward (denoiser.py:24-44, 69-78) -> CFG."""
     xin = torch.cat([x, x])
     s = torch.cat([sigma, sigma])
     c_all = {k: torch.cat((uc[k], cond[k]), 0) for k in cond}
-    idx = sigma_to_idx(s, table)
-    s = table[idx]                                    # possibly_quantize_sigma
+    if discrete:
+        s = table[sigma_to_idx(s, table)]             # possibly_quantize_sigma
     sb = s.view(-1, *([1] * (x.ndim - 1)))
-    c_in = 1 / (sb ** 2 + 1.0) ** 0.5
-    c_noise = sigma_to_idx(s, table)                  # quantize_c_noise -> index 0..999
-    out = net(xin * c_in, c_noise, c_all) * (-sb) + xin
+    c_skip, c_out, c_in, c_noise = denoiser_scaling(scaling, sb)
+    c_noise = c_noise.reshape(s.shape)
+    if discrete and quantize_c_noise:
+        c_noise = sigma_to_idx(c_noise, table)        # quantize_c_noise -> index 0..999
+    out = net(xin * c_in, c_noise, c_all) * c_out + xin * c_skip
     x_u, x_c = out.chunk(2)
     return x_u + scale * (x_c - x_u)
 
 
 def edm_euler_sample(net, z, cond, uc, num_steps=250, scale=6.5, trace=None, s_churn=0.0, s_tmin=0.0, s_tmax=float('inf'), s_noise=1.0,
-                     step_noise=None):
+                     step_noise=None, **denoiser_kw):
     """EulerEDMSampler.__call__ (sgm/modules/diffusionmodules/sampling.py:82-130,211-215).  s_churn = 0: gamma = 0, deterministic after z.
     s_churn > 0 (r6): gamma_i = min(s_churn / (num_sigmas - 1), sqrt 2 - 1) where s_tmin <= sigma_i <= s_tmax; sigma_hat = sigma (1 + gamma),
     x += randn * s_noise * sqrt(sigma_hat^2 - sigma^2) before the denoiser runs at sigma_hat; step_noise(i) supplies the draw of step i."""
@@ -86,7 +99,7 @@ def edm_euler_sample(net, z, cond, uc, num_steps=250, scale=6.5, trace=None, s_c
             eps = (step_noise(i) if step_noise is not None else torch.randn_like(x)) * s_noise
             x = x + eps * ((sigma_hat ** 2 - sigma ** 2) ** 0.5).view(-1, *([1] * (x.ndim - 1)))
             sigma = sigma_hat
-        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table)
+        den = edm_denoise_cfg(net, x, sigma, cond, uc, scale, table, **denoiser_kw)
         sb = sigma.view(-1, *([1] * (x.ndim - 1)))
         d = (x - den) / sb
         x = x + d * (nxt - sigma).view(-1, *([1] * (x.ndim - 1)))

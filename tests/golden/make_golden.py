@@ -459,6 +459,25 @@ def sec_more_samplers():
         check(f'{cls.__name__} with IdentityGuider final latent', y_or, y_ref, 2e-4)
         save(name, final=y_ref, net_calls=np.array(len(calls) - n0))
 
+    # the other denoiser scalings (denoiser_scaling.py:14-59) and the continuous Denoiser (denoiser.py:13-42), under Euler + CFG
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    sc = 'sgm.modules.diffusionmodules.denoiser_scaling.'
+    for name, kind, discrete, qcn in (('euler_vscaling_tiny_8', 'v', True, True), ('euler_vscaling_edmcnoise_tiny_8', 'v_edm', True, False),
+                                      ('euler_edmscaling_cont_tiny_8', 'edm', False, False)):
+        target = {'v': 'VScaling', 'v_edm': 'VScalingWithEDMcNoise', 'edm': 'EDMScaling'}[kind]
+        d2 = (DiscreteDenoiser(scaling_config={'target': sc + target}, num_idx=1000, discretization_config=dc, do_append_zero=False,
+                               quantize_c_noise=qcn, flip=True) if discrete else Denoiser(scaling_config={'target': sc + target}))
+        labels = []
+
+        def net2(x, t, c, **kw):
+            labels.append(float(t[0]))
+            return m(x, t, c)
+        sampler = S.EulerEDMSampler(discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu')
+        y_ref = sampler(lambda x, s, c: d2(net2, x, s, c), z.clone(), cond, uc)
+        y_or = osamp.edm_euler_sample(onet, z.clone(), cond, uc, steps, 6.5, scaling=kind, discrete=discrete, quantize_c_noise=qcn)
+        check(f'EulerEDM + {target} ({"discrete" if discrete else "continuous"}) final latent', y_or, y_ref, 2e-4)
+        save(name, final=y_ref, labels=np.array(labels, dtype=np.float32))
+
     # LinearMultistepSampler (deterministic, order 4 and 2)
     for order in (4, 2):
         y_ref = run(S.LinearMultistepSampler(order=order, discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))

@@ -314,6 +314,9 @@ def test_oracle_other_sgm_samplers_match_reference_goldens():
     assert rel_l2(osamp.dpmpp2m_sample(net, z.clone(), cond, uc, 8, 6.5), g['final']) < 1e-4
     assert rel_l2(osamp.edm_euler_sample(net, z.clone(), cond, cond, 8, 1.0), golden('euler_identity_tiny_8')['final']) < 1e-4
     assert rel_l2(osamp.edm_heun_sample(net, z.clone(), cond, cond, 8, 1.0), golden('heun_identity_tiny_8')['final']) < 1e-4
+    for tag, kw in (('euler_vscaling_tiny_8', dict(scaling='v')), ('euler_vscaling_edmcnoise_tiny_8', dict(scaling='v_edm', quantize_c_noise=False)),
+                    ('euler_edmscaling_cont_tiny_8', dict(scaling='edm', discrete=False))):
+        assert rel_l2(osamp.edm_euler_sample(net, z.clone(), cond, uc, 8, 6.5, **kw), golden(tag)['final']) < 1e-4, tag
     for order in (4, 2):
         g = golden('lms%d_tiny_8' % order)
         assert rel_l2(osamp.linear_multistep_sample(net, z.clone(), cond, uc, 8, 6.5, order), g['final']) < 1e-4, order

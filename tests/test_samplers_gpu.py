@@ -2,6 +2,7 @@
 The loops are chaotic amplifiers of rounding error, so the tolerance is on the FINAL latent relative to its norm:
 bf16 network inside an fp32 sampler state: rel-L2 <= 1e-2 after 10..250 steps (measured 1.6e-4 .. 3.2e-4: the samplers
 contract, the per-step network error ~1e-3 does not compound)."""
+import numpy as np
 import pytest
 import torch
 
@@ -135,6 +136,23 @@ def test_other_sgm_samplers_vs_reference_goldens(hip_lib):
         res[tag] = (rel_l2(y.cpu(), g['final']),)
     y = S.EulerEDMSampler(num_steps=8, guider=S.IdentityGuider())(den.bind(m), z.clone(), cond, None)      # a bound pair: still the un-doubled loop
     assert rel_l2(y.cpu(), golden('euler_identity_tiny_8')['final']) < 1e-2
+    # the other denoiser scalings and the continuous Denoiser (denoiser.py:13-78, denoiser_scaling.py:14-59): the network must see the reference's
+    # noise labels (table indices / 0.25 log sigma) and the sampler must leave the fused Eps loop
+    for tag, dn in (('euler_vscaling_tiny_8', S.DiscreteDenoiser(scaling=S.VScaling())),
+                    ('euler_vscaling_edmcnoise_tiny_8', S.DiscreteDenoiser(scaling=S.VScalingWithEDMcNoise(), quantize_c_noise=False)),
+                    ('euler_edmscaling_cont_tiny_8', S.Denoiser(scaling=S.EDMScaling()))):
+        g = golden(tag)
+        labels = []
+
+        class Net:                                    # an opaque network wrapper: records the noise label of every call
+            def __call__(self, x, t, c, **kw):
+                labels.append(float(t[0]))
+                return m(x, t, c)
+        y = S.EulerEDMSampler(**cfg)(dn.bind(Net()), z.clone(), cond, uc)
+        res[tag] = (rel_l2(y.cpu(), g['final']),)
+        assert np.allclose(np.array(labels, dtype=np.float32), g['labels'], rtol=1e-5, atol=1e-6), (tag, labels[:3], g['labels'][:3])
+        y2 = S.EulerEDMSampler(**cfg)(dn, z.clone(), cond, uc, network=m)                  # network=: the package's DiT, still the generic loop
+        assert rel_l2(y2.cpu(), g['final']) < 1e-2
     print('other samplers vs reference:', {k: tuple(round(v, 5) for v in e) for k, e in res.items()})
     for k, e in res.items():
         assert max(e) < 1e-2, (k, e)
