@@ -1,7 +1,7 @@
 """EDM-style sampling stack of the released T23D checkpoint, device-resident.
 
 Mirrors the reference's sgm surface for this path (same class names / call signatures):
-  LegacyDDPMDiscretization   sgm/modules/diffusionmodules/discretizer.py:42-69
+  LegacyDDPMDiscretization, EDMDiscretization   sgm/modules/diffusionmodules/discretizer.py:27-69
   Denoiser / DiscreteDenoiser + EpsScaling / VScaling / VScalingWithEDMcNoise / EDMScaling   sgm/modules/diffusionmodules/denoiser.py:13-78, denoiser_scaling.py:14-59
   VanillaCFG                 sgm/modules/diffusionmodules/guiders.py:24-42
   EulerEDMSampler            sgm/modules/diffusionmodules/sampling.py:82-130,211-215
@@ -49,6 +49,18 @@ class LegacyDDPMDiscretization:
         if do_append_zero:
             s = torch.cat([s, s.new_zeros([1])])
         return s if not flip else torch.flip(s, (0,))
+
+
+class EDMDiscretization(LegacyDDPMDiscretization):
+    """discretizer.py:27-39: Karras' rho schedule, sigma_i = (sigma_max^(1/rho) + i / (n - 1) (sigma_min^(1/rho) - sigma_max^(1/rho)))^rho."""
+
+    def __init__(self, sigma_min=0.002, sigma_max=80.0, rho=7.0):
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n, device="cpu"):
+        ramp = torch.linspace(0, 1, n, device=device)
+        lo, hi = self.sigma_min ** (1 / self.rho), self.sigma_max ** (1 / self.rho)
+        return (hi + ramp * (lo - hi)) ** self.rho
 
 
 class VanillaCFG:

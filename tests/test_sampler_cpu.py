@@ -59,3 +59,18 @@ def test_explicit_routes():
     o = Opaque()
     o._ln3d_pair = (e.denoiser, e.model)                  # explicit opt-in
     assert _find_pair(o) == (e.denoiser, e.model)
+
+
+def test_edm_discretization_is_the_karras_rho_schedule():
+    """discretizer.py:27-39 on its published defaults: endpoints, monotone, the appended zero / flip plumbing shared with the legacy table."""
+    import torch
+    from ln3diff_amd.sgm.sampling import EDMDiscretization
+    d = EDMDiscretization()
+    s = d(10)
+    assert s.shape == (11,) and float(s[-1]) == 0.0
+    assert abs(float(s[0]) - 80.0) < 1e-4 and abs(float(s[9]) - 0.002) < 1e-7
+    assert bool((s[:-1][1:] < s[:-1][:-1]).all())
+    ramp = torch.linspace(0, 1, 10)
+    ref = (80.0 ** (1 / 7.0) + ramp * (0.002 ** (1 / 7.0) - 80.0 ** (1 / 7.0))) ** 7.0
+    assert torch.equal(d.get_sigmas(10), ref)
+    assert torch.equal(d(10, do_append_zero=False, flip=True), torch.flip(ref, (0,)))
