@@ -478,6 +478,14 @@ def sec_more_samplers():
         check(f'EulerEDM + {target} ({"discrete" if discrete else "continuous"}) final latent', y_or, y_ref, 2e-4)
         save(name, final=y_ref, labels=np.array(labels, dtype=np.float32))
 
+    # EDMDiscretization (discretizer.py:27-39): the product's class against the reference's, bit for bit (no fixture needed)
+    from sgm.modules.diffusionmodules.discretizer import EDMDiscretization as RefEDM
+    from ln3diff_amd.sgm.sampling import EDMDiscretization as OurEDM
+    for n_ in (5, 10, 50):
+        check(f'EDMDiscretization n={n_}', OurEDM()(n_), RefEDM()(n_), 0)
+        check(f'EDMDiscretization n={n_} flipped', OurEDM()(n_, do_append_zero=False, flip=True), RefEDM()(n_, do_append_zero=False, flip=True), 0)
+    check('EDMDiscretization (0.01, 20, 5)', OurEDM(0.01, 20.0, 5.0)(13), RefEDM(0.01, 20.0, 5.0)(13), 0)
+
     # LinearMultistepSampler (deterministic, order 4 and 2)
     for order in (4, 2):
         y_ref = run(S.LinearMultistepSampler(order=order, discretization_config=dc, num_steps=steps, guider_config=gc, device='cpu'))
